@@ -1,0 +1,171 @@
+/*
+ * eslam_hip.h - C ABI of the MI355X (gfx950) implementation of ESLAM's per-iteration rendering hot path.
+ *
+ * The reference (MohammadJohari/myslam) is 100 % Python on PyTorch and has no FFI of its own; its boundary for
+ * this path is the in-process Python API  Renderer.render_batch_ray / get_samples / Decoders.forward.
+ * This header is the C-ABI a binding for that API calls (myslam_amd/_hip.py is the ctypes binding we ship,
+ * INTEGRATION.md shows the stub a reference maintainer would add).  Each entry point names the reference
+ * lines it replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to float32 / int64 data unless the name ends in _host;
+ *   - `stream` is a hipStream_t (NULL = default stream); every call only enqueues work on it: no allocation,
+ *     no synchronisation, no host<->device copy, so a caller may capture a call into a hipGraph;
+ *   - return value 0 = ok, anything else = error; eslam_last_error() gives the message (thread local);
+ *   - tri-planes are the reference's 6 lists x 2 levels flattened in `all_planes` order:
+ *       index = 2*g + level,  g in (planes_xy, planes_xz, planes_yz, c_planes_xy, c_planes_xz, c_planes_yz),
+ *     each a logical [1, C=32, h, w] tensor described by element strides, so both NCHW-contiguous tensors
+ *     (what reference src/ESLAM.py:201-210 allocates) and channels-last ones (what myslam_amd.scene allocates;
+ *     one texel = 128 contiguous bytes, the fast path) are accepted without a copy;
+ *   - decoder parameters are the reference's tensors (src/networks/decoders.py:47-60), row-major [out, in].
+ */
+#ifndef ESLAM_HIP_H
+#define ESLAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ESLAM_ABI_VERSION 1
+#define ESLAM_C_DIM 32          /* feature channels per plane (configs/ESLAM.yaml:77)               */
+#define ESLAM_HIDDEN 16         /* decoder hidden width (src/networks/decoders.py:39)               */
+#define ESLAM_FEAT (2 * ESLAM_C_DIM)   /* coarse || fine                                          */
+#define ESLAM_N_PLANES 12
+#define ESLAM_MAX_SAMPLES 256   /* samples per ray supported by the per-ray kernels                  */
+/* floats in the flat decoder-gradient vector, in the order of eslam_decoders_t (beta excluded)      */
+#define ESLAM_N_DEC_PARAMS (2 * (16 * 64 + 16 + 16 * 16 + 16) + (1 * 16 + 1) + (3 * 16 + 3))
+
+typedef void* eslam_stream_t;
+
+typedef struct {
+    const float* data;      /* element [0,0,0,0]                                                  */
+    float* grad;            /* same strides as data; kernels ACCUMULATE (+=) into it; may be NULL  */
+    int32_t h, w;
+    int64_t stride_c, stride_y, stride_x;   /* in elements                                         */
+} eslam_plane_t;
+
+typedef struct {            /* src/networks/decoders.py:47-60                                      */
+    const float* w1;  const float* b1;      /* linears.0        [16,64],[16]                        */
+    const float* w2;  const float* b2;      /* linears.1        [16,16],[16]                        */
+    const float* w3;  const float* b3;      /* output_linear    [1,16],[1]                          */
+    const float* cw1; const float* cb1;     /* c_linears.0      [16,64],[16]                        */
+    const float* cw2; const float* cb2;     /* c_linears.1      [16,16],[16]                        */
+    const float* cw3; const float* cb3;     /* c_output_linear  [3,16],[3]                          */
+    const float* beta;                      /* [1] (a device copy of the int when not learnable)    */
+} eslam_decoders_t;
+
+const char* eslam_last_error(void);
+int eslam_abi_version(void);
+
+/* K1 - pixel pick + back-projection.  Replaces src/common.py:87-153 (get_samples and helpers) with the
+ * torch.randint draw of common.py:108 lifted to the caller: indices[b*n] are flat positions inside the crop
+ * window [H0,H1) x [W0,W1), row-major, image k owning indices[k*n .. (k+1)*n).
+ * depths [b,H,W], colors [b,H,W,3] contiguous; c2ws [b,4,4] row-major.
+ * Outputs rays_o/rays_d [b*n,3], depth [b*n], color [b*n,3].                                        */
+int eslam_sample_rays(const int64_t* indices, int b, int n, int H0, int H1, int W0, int W1, int H, int W,
+                      float fx, float fy, float cx, float cy, const float* c2ws, const float* depths,
+                      const float* colors, float* rays_o, float* rays_d, float* depth, float* color,
+                      eslam_stream_t stream);
+
+/* Backward of K1 w.r.t. the camera matrices (autograd of common.py:92-97): g_c2ws [b,4,4] is OVERWRITTEN
+ * with  d/dc2w ( <g_rays_o, rays_o> + <g_rays_d, rays_d> );  rows/cols outside [:3,:4] are zero.     */
+int eslam_sample_rays_bwd(const int64_t* indices, int b, int n, int H0, int W0, int W1, float fx, float fy,
+                          float cx, float cy, const float* g_rays_o, const float* g_rays_d, float* g_c2ws,
+                          eslam_stream_t stream);
+
+/* Whole-image rays.  Replaces src/common.py:183-201 (get_rays).  rays_o/rays_d [H*W,3].             */
+int eslam_image_rays(int H, int W, float fx, float fy, float cx, float cy, const float* c2w, float* rays_o,
+                     float* rays_d, eslam_stream_t stream);
+
+/* a2 - AABB exit distance  min_axis max_side (bound - o)/d.  Replaces the caller-side pre-filter arithmetic
+ * of src/Mapper.py:322-328 and src/Tracker.py:175-181.  t_exit [R].                                  */
+int eslam_aabb_exit(const float* rays_o, const float* rays_d, int R, const float* bound6_host, float* t_exit,
+                    eslam_stream_t stream);
+
+/* K3 - depth-guided sampler.  Replaces src/utils/Renderer.py:85-105 and perturbation (:46-61) for rays with
+ * gt_depth > 0; rows of rays with gt_depth <= 0 are left untouched (K4 fills them).
+ * t_free[n_strat], t_surf[n_imp]: the two linspace(0,1,.) vectors (device); t_rand [R,S] uniform numbers or
+ * NULL for perturb = False.  z_vals [R,S] out, S = n_strat + n_imp.  Bit-exact vs the reference arithmetic
+ * (truncation is a double because Renderer.py:97 forms 1.5*truncation and 3*truncation as Python floats).    */
+int eslam_sample_z(const float* gt_depth, int R, int n_strat, int n_imp, double truncation, const float* t_free,
+                   const float* t_surf, const float* t_rand, float* z_vals, eslam_stream_t stream);
+
+/* K4 - importance sampler for rays with gt_depth <= 0.  Replaces src/utils/Renderer.py:108-134 and
+ * src/common.py:41-77 (sample_pdf, det=False).  Only geometry planes + SDF decoder are evaluated, no grad.
+ * t_rand_uni [R,n_strat] or NULL, u [R,n_imp]; rows of rays with gt_depth > 0 are ignored / left untouched. */
+int eslam_importance_z(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
+                       const float* rays_o, const float* rays_d, const float* gt_depth, int R, int n_strat,
+                       int n_imp, const float* t_free, const float* t_rand_uni, const float* u, float* z_vals,
+                       eslam_stream_t stream);
+
+/* K5-K7 forward.  Replaces src/utils/Renderer.py:136-147 + src/networks/decoders.py:64-146 +
+ * src/common.py:204-218:  pts = o + d z -> normalise -> tri-plane bilinear gather (border, align_corners) ->
+ * SDF / colour MLPs -> sdf2alpha -> transmittance scan -> composite.
+ * Outputs: depth [R], rgb [R,3], sdf [R,S].  For a later backward pass also raw_rgb [R,S,3] (sigmoid outputs)
+ * and feat [R*S,128] (geometry 64 || colour 64 features per sample); both may be NULL for inference.        */
+int eslam_render_fwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
+                     const float* rays_o, const float* rays_d, const float* z_vals, int R, int S, float* depth,
+                     float* rgb, float* sdf, float* raw_rgb, float* feat, eslam_stream_t stream);
+
+/* Bytes of scratch eslam_render_bwd / eslam_decode_bwd need for n_points = R*S points.               */
+int64_t eslam_bwd_workspace_bytes(int64_t n_points);
+
+/* K8 backward of eslam_render_fwd (autograd of the lines above).
+ * Upstream: g_depth [R], g_rgb [R,3], g_sdf [R,S] (any may be NULL = zero).
+ * Accumulates into planes[i].grad (where non-NULL), OVERWRITES g_dec [ESLAM_N_DEC_PARAMS] (order of
+ * eslam_decoders_t: w1,b1,w2,b2,w3,b3,cw1,...,cb3) and g_beta [1], and when g_rays_o / g_rays_d are
+ * non-NULL overwrites them ([R,3] each) with the gradient through pts = o + d z.  z_vals carries no gradient
+ * (Renderer.py builds it under no_grad / from gt_depth).  workspace: eslam_bwd_workspace_bytes(R*S) bytes. */
+int eslam_render_bwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
+                     const float* rays_o, const float* rays_d, const float* z_vals, int R, int S,
+                     const float* sdf, const float* raw_rgb, const float* feat, const float* g_depth,
+                     const float* g_rgb, const float* g_sdf, float* g_dec, float* g_beta, float* g_rays_o,
+                     float* g_rays_d, void* workspace, eslam_stream_t stream);
+
+/* Decoder-only query.  Replaces src/networks/decoders.py:127-146 (Decoders.forward), the entry used by
+ * src/utils/Mesher.py:151 on up to 500k points.  pts [N,3] world coordinates -> raw [N,4] = (r,g,b,sdf).
+ * sdf_only != 0 evaluates geometry planes + SDF decoder only (decoders.py:87-105) and writes raw [N,1].
+ * feat [N,128] optional (needed only for eslam_decode_bwd).                                          */
+int eslam_decode_fwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
+                     const float* pts, int64_t N, int sdf_only, float* raw, float* feat, eslam_stream_t stream);
+
+/* Backward of eslam_decode_fwd: g_raw [N,4] upstream, raw [N,4] the forward output.  Same gradient outputs as
+ * eslam_render_bwd, with g_pts [N,3] (may be NULL) instead of ray gradients.                          */
+int eslam_decode_bwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
+                     const float* pts, int64_t N, const float* raw, const float* feat, const float* g_raw,
+                     float* g_dec, float* g_pts, void* workspace, eslam_stream_t stream);
+
+/* Caller-side loss of one optimisation iteration, value and upstream gradients in two small launches and
+ * without the boolean-mask host syncs of the PyTorch formulation.  Replaces src/Mapper.py:110-144 (sdf_losses)
+ * + :337-346, and src/Tracker.py:114-148 + :197-204 when ray_mask is given.
+ *   ray_mask == NULL (mapping): SDF and depth terms over rays with gt_depth > 0, colour term over all rays.
+ *   ray_mask != NULL (tracking): uint8 [R], the 10x-median outlier mask of Tracker.py:193-195 computed by the
+ *                                caller; SDF, depth and colour terms all run over the masked rays.
+ * weights5_host = {w_sdf_fs, w_sdf_center, w_sdf_tail, w_depth, w_color}  (configs/ESLAM.yaml:29-33,53-57).
+ * Outputs: loss [1]; g_depth [R], g_rgb [R,3], g_sdf [R,S] = d loss / d (depth, rgb, sdf) (overwritten).
+ * Means over empty sets give NaN exactly as torch.mean does.  scratch: 64 bytes, any contents.            */
+int eslam_mapping_loss(const float* depth, const float* rgb, const float* sdf, const float* z_vals,
+                       const float* gt_depth, const float* gt_color, int R, int S, double truncation,
+                       const float* weights5_host, int unused_flags, const uint8_t* ray_mask, float* loss,
+                       float* g_depth, float* g_rgb, float* g_sdf, void* scratch, eslam_stream_t stream);
+
+/* The two phases of eslam_mapping_loss separately, for ray-sharded data parallelism: every rank runs
+ * eslam_loss_reduce on its shard, the ESLAM_LOSS_ACC floats of `acc` (set sizes and squared-error sums) are
+ * summed over ranks with one tiny all-reduce, then eslam_loss_grad produces upstream gradients scaled by the GLOBAL
+ * set sizes, so the summed gradients equal those of the unsharded batch.  acc must be zeroed by the caller
+ * before eslam_loss_reduce (it accumulates).                                                               */
+#define ESLAM_LOSS_ACC 16
+int eslam_loss_reduce(const float* depth, const float* rgb, const float* sdf, const float* z_vals,
+                      const float* gt_depth, const float* gt_color, int R, int S, double truncation,
+                      const uint8_t* ray_mask, float* acc, eslam_stream_t stream);
+int eslam_loss_grad(const float* depth, const float* rgb, const float* sdf, const float* z_vals,
+                    const float* gt_depth, const float* gt_color, int R, int S, double truncation,
+                    const float* weights5_host, const uint8_t* ray_mask, const float* acc, float* loss,
+                    float* g_depth, float* g_rgb, float* g_sdf, eslam_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESLAM_HIP_H */

@@ -1,0 +1,170 @@
+"""ctypes binding of the C-ABI library (include/eslam_hip.h) - the only door to the HIP kernels.
+
+The library is loaded lazily, once per process (the reference pickles its Renderer into two spawned
+processes, reference src/ESLAM.py:246-260, so nothing process-specific may live on the Python objects).
+There is NO fallback: if the shared object is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libeslam_hip.so")
+
+N_DEC_PARAMS = 2692
+N_PLANES = 12
+
+
+class PlaneDesc(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("h", ctypes.c_int32), ("w", ctypes.c_int32),
+                ("stride_c", ctypes.c_int64), ("stride_y", ctypes.c_int64), ("stride_x", ctypes.c_int64)]
+
+
+class DecodersDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in
+                ("w1", "b1", "w2", "b2", "w3", "b3", "cw1", "cb1", "cw2", "cb2", "cw3", "cb3", "beta")]
+
+
+PlaneArray = PlaneDesc * N_PLANES
+Bound6 = ctypes.c_float * 6
+
+_vp, _i, _i64, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
+_PP = ctypes.POINTER(PlaneDesc)
+_DP = ctypes.POINTER(DecodersDesc)
+_BP = ctypes.POINTER(ctypes.c_float)
+
+# name -> (restype, argtypes); must list every symbol declared in include/eslam_hip.h
+SIGNATURES = {
+    "eslam_last_error": (ctypes.c_char_p, []),
+    "eslam_abi_version": (_i, []),
+    "eslam_sample_rays": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "eslam_sample_rays_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
+    "eslam_image_rays": (_i, [_i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
+    "eslam_aabb_exit": (_i, [_vp, _vp, _i, _BP, _vp, _vp]),
+    "eslam_sample_z": (_i, [_vp, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp]),
+    "eslam_importance_z": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "eslam_render_fwd": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "eslam_bwd_workspace_bytes": (_i64, [_i64]),
+    "eslam_render_bwd": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                              _vp, _vp]),
+    "eslam_decode_fwd": (_i, [_PP, _DP, _BP, _vp, _i64, _i, _vp, _vp, _vp]),
+    "eslam_decode_bwd": (_i, [_PP, _DP, _BP, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "eslam_mapping_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _BP, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "eslam_loss_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp]),
+    "eslam_loss_grad": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _BP, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load_library(path=None):
+    """dlopen the library and attach prototypes.  Does not need a GPU (used by the CPU test suite)."""
+    global _lib
+    with _lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = path or LIB_PATH
+        if not os.path.exists(p):
+            raise RuntimeError(
+                f"HIP extension not built: {p} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C myslam_amd/csrc`). There is no CPU fallback for the render path.")
+        lib = ctypes.CDLL(p)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        if lib.eslam_abi_version() != 1:
+            raise RuntimeError(f"ABI mismatch: library reports version {lib.eslam_abi_version()}, binding expects 1")
+        if path is None:
+            _lib = lib
+        return lib
+
+
+def lib():
+    return _lib if _lib is not None else load_library()
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().eslam_last_error()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_handle(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_gpu_f32(name, t):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a tensor on the GPU (got device {t.device}); the HIP render path has "
+                           "no CPU fallback")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
+
+
+def make_planes(all_planes, grads=None):
+    """all_planes: the reference's 6-tuple of [coarse, fine] lists -> (PlaneArray, keepalive list)."""
+    arr = PlaneArray()
+    flat = []
+    k = 0
+    for g in range(6):
+        grp = all_planes[g]
+        if len(grp) != 2:
+            raise RuntimeError(f"plane group {g}: expected [coarse, fine], got {len(grp)} levels")
+        for lvl in range(2):
+            p = grp[lvl]
+            require_gpu_f32(f"plane[{g}][{lvl}]", p)
+            if p.dim() != 4 or p.shape[0] != 1 or p.shape[1] != 32:
+                raise RuntimeError(f"plane[{g}][{lvl}]: expected shape [1,32,h,w], got {tuple(p.shape)}")
+            d = arr[k]
+            d.data = p.data_ptr()
+            d.h, d.w = int(p.shape[2]), int(p.shape[3])
+            d.stride_c, d.stride_y, d.stride_x = (int(v) for v in p.stride()[1:])
+            if grads is not None:
+                gr = grads[k]
+                if gr.stride() != p.stride() or gr.shape != p.shape:
+                    raise RuntimeError("plane gradient buffer must have the plane's shape and strides")
+                d.grad = gr.data_ptr()
+            else:
+                d.grad = None
+            flat.append(p)
+            k += 1
+    return arr, flat
+
+
+DEC_FIELDS = (("w1", "linears.0.weight", (16, 64)), ("b1", "linears.0.bias", (16,)),
+              ("w2", "linears.1.weight", (16, 16)), ("b2", "linears.1.bias", (16,)),
+              ("w3", "output_linear.weight", (1, 16)), ("b3", "output_linear.bias", (1,)),
+              ("cw1", "c_linears.0.weight", (16, 64)), ("cb1", "c_linears.0.bias", (16,)),
+              ("cw2", "c_linears.1.weight", (16, 16)), ("cb2", "c_linears.1.bias", (16,)),
+              ("cw3", "c_output_linear.weight", (3, 16)), ("cb3", "c_output_linear.bias", (3,)))
+
+
+def make_decoders(params, beta):
+    """params: 12 tensors in DEC_FIELDS order; beta: device tensor [1]."""
+    d = DecodersDesc()
+    keep = []
+    for (field, name, shape), t in zip(DEC_FIELDS, params):
+        require_gpu_f32(name, t)
+        if tuple(t.shape) != shape:
+            raise RuntimeError(f"{name}: expected shape {shape}, got {tuple(t.shape)} (c_dim=32, hidden=16, 2 blocks)")
+        if not t.is_contiguous():
+            t = t.contiguous()
+        keep.append(t)
+        setattr(d, field, t.data_ptr())
+    require_gpu_f32("beta", beta)
+    d.beta = beta.data_ptr()
+    keep.append(beta)
+    return d, keep
+
+
+def make_bound(bound_host):
+    """bound_host: 6 Python floats (x0,x1,y0,y1,z0,z1)."""
+    return Bound6(*[float(v) for v in bound_host])

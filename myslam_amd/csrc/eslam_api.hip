@@ -1,0 +1,62 @@
+// Error plumbing and argument validation shared by the C-ABI entry points.
+#include <stdarg.h>
+#include <stdio.h>
+#include "eslam_common.h"
+
+static thread_local char g_err[512] = "";
+
+void eslam_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int eslam_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        eslam_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return 2;
+    }
+    return 0;
+}
+
+extern "C" const char* eslam_last_error(void) { return g_err; }
+extern "C" int eslam_abi_version(void) { return ESLAM_ABI_VERSION; }
+
+// A plane is "channels-last" when one texel's 32 channels are contiguous and texels along x are adjacent.
+bool eslam_planes_channels_last(const eslam_plane_t* planes, int first, int count) {
+    for (int i = first; i < first + count; ++i) {
+        const eslam_plane_t& p = planes[i];
+        if (p.stride_c != 1 || p.stride_x != ESLAM_C_DIM) return false;
+        if (((uintptr_t)p.data & 15) != 0 || (p.stride_y & 3) != 0) return false;
+        if (p.grad && ((uintptr_t)p.grad & 15) != 0) return false;
+    }
+    return true;
+}
+
+// Shapes must match what the kernels and their launch grids assume before anything is launched.
+int eslam_validate_planes(const eslam_plane_t* planes, int first, int count) {
+    for (int i = first; i < first + count; ++i) {
+        const eslam_plane_t& p = planes[i];
+        if (!p.data) {
+            eslam_set_error("plane %d: null data pointer", i);
+            return 1;
+        }
+        if (p.h < 2 || p.w < 2) {
+            eslam_set_error("plane %d: needs h,w >= 2 (got %d x %d)", i, p.h, p.w);
+            return 1;
+        }
+        if (p.stride_c <= 0 || p.stride_y <= 0 || p.stride_x <= 0) {
+            eslam_set_error("plane %d: strides must be positive", i);
+            return 1;
+        }
+        const int64_t extent = (ESLAM_C_DIM - 1) * p.stride_c + (int64_t)(p.h - 1) * p.stride_y +
+                               (int64_t)(p.w - 1) * p.stride_x + 1;
+        if (extent >= ((int64_t)1 << 31)) {
+            eslam_set_error("plane %d: extent %lld elements exceeds 32-bit offsets", i, (long long)extent);
+            return 1;
+        }
+    }
+    return 0;
+}

@@ -1,0 +1,137 @@
+// Shared device helpers for the ESLAM render kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/eslam_hip.h"
+
+#define WAVE 64
+#define NPL ESLAM_N_PLANES
+
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+// Kernel-argument copy of the 12 plane descriptors (kernarg segment -> scalar loads, wave-uniform).
+struct PlaneSet {
+    eslam_plane_t p[NPL];
+};
+
+struct Bound {
+    float lo[3];
+    float inv_len_unused[3];   // kept for layout stability
+    float hi[3];
+};
+
+// Decoder weights staged in LDS, one copy per workgroup.  Row-major as in the reference tensors.
+// Layout (floats):  per decoder d (0 = sdf, 1 = rgb) at d*DEC_LDS:
+//   W1 [16][64] @0, b1 [16] @1024, W2 [16][16] @1040, b2 [16] @1296, W3 [4][16] @1312 (rows >= n_out zero),
+//   b3 [4] @1376 (entries >= n_out zero)
+#define DEC_W1 0
+#define DEC_B1 1024
+#define DEC_W2 1040
+#define DEC_B2 1296
+#define DEC_W3 1312
+#define DEC_B3 1376
+#define DEC_LDS 1380
+
+__device__ __forceinline__ void stage_decoder_weights(float* lds, const eslam_decoders_t& dec, int tid, int nthreads) {
+    for (int d = 0; d < 2; ++d) {
+        const float* w1 = d ? dec.cw1 : dec.w1;
+        const float* b1 = d ? dec.cb1 : dec.b1;
+        const float* w2 = d ? dec.cw2 : dec.w2;
+        const float* b2 = d ? dec.cb2 : dec.b2;
+        const float* w3 = d ? dec.cw3 : dec.w3;
+        const float* b3 = d ? dec.cb3 : dec.b3;
+        const int nout = d ? 3 : 1;
+        float* L = lds + d * DEC_LDS;
+        for (int i = tid; i < 1024; i += nthreads) L[DEC_W1 + i] = w1[i];
+        for (int i = tid; i < 256; i += nthreads) L[DEC_W2 + i] = w2[i];
+        for (int i = tid; i < 16; i += nthreads) {
+            L[DEC_B1 + i] = b1[i];
+            L[DEC_B2 + i] = b2[i];
+        }
+        for (int i = tid; i < 64; i += nthreads) L[DEC_W3 + i] = (i < nout * 16) ? w3[i] : 0.0f;
+        for (int i = tid; i < 4; i += nthreads) L[DEC_B3 + i] = (i < nout) ? b3[i] : 0.0f;
+    }
+}
+
+// normalize_3d_coordinate (reference src/common.py:215-217), same operation order.
+__device__ __forceinline__ float norm_coord(float p, float lo, float hi) {
+    return __fsub_rn(__fmul_rn(__fdiv_rn(__fsub_rn(p, lo), __fsub_rn(hi, lo)), 2.0f), 1.0f);
+}
+
+// grid_sample(align_corners=True, padding_mode='border') coordinate rule for one axis of size n:
+// ix = clamp(((u+1)/2)*(n-1), 0, n-1);  i0 = floor(ix); i1 = min(i0+1, n-1); t = ix - i0.
+// `inside` is the gradient gate of ATen's clip_coordinates_set_grad (strictly inside only).
+struct AxisCoord {
+    int i0, i1;
+    float t;
+    bool inside;
+};
+
+__device__ __forceinline__ AxisCoord axis_coord(float u, int n) {
+    const float nm1 = (float)(n - 1);
+    float x = ((u + 1.0f) * 0.5f) * nm1;
+    AxisCoord a;
+    a.inside = (x > 0.0f) && (x < nm1);
+    x = fminf(fmaxf(x, 0.0f), nm1);
+    const float f = floorf(x);
+    a.i0 = (int)f;
+    a.i1 = min(a.i0 + 1, n - 1);
+    a.t = x - f;
+    return a;
+}
+
+// Which two point coordinates index plane orientation o (0 = xy, 1 = xz, 2 = yz): first -> width, second -> height
+// (reference src/networks/decoders.py:79-81).
+#define ORIENT_U(o, x, y, z) ((o) == 2 ? (y) : (x))
+#define ORIENT_V(o, x, y, z) ((o) == 0 ? (y) : (z))
+
+// Ordering point for LDS traffic between lanes of ONE wave (no other wave touches the region): DS operations of a
+// wave are executed in issue order, so this only has to stop the compiler from moving accesses across it.
+#define WAVE_SYNC()                                              \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+    } while (0)
+
+// A wave-uniform zero the optimiser cannot fold (used to pin scalar loads inside loops, see gather_features).
+__device__ __forceinline__ int opaque_zero(int loop_var) {
+    int z = __builtin_amdgcn_readfirstlane(loop_var);
+    asm volatile("s_and_b32 %0, %0, 0" : "+s"(z));
+    return z;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, WAVE);
+    return v;
+}
+
+// inclusive product scan over the 64 lanes of a wave
+__device__ __forceinline__ float wave_incl_prod(float v, int lane) {
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        float o = __shfl_up(v, d, WAVE);
+        if (lane >= d) v *= o;
+    }
+    return v;
+}
+
+// inclusive suffix sum (lane i gets sum over lanes >= i)
+__device__ __forceinline__ float wave_incl_suffix_sum(float v, int lane) {
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        float o = __shfl_down(v, d, WAVE);
+        if (lane + d < WAVE) v += o;
+    }
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float4_t mfma16(float a, float b, float4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// thread-local error string shared by the API translation units
+void eslam_set_error(const char* fmt, ...);
+int eslam_check_launch(const char* what);

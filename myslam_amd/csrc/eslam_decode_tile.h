@@ -1,0 +1,147 @@
+// Tri-plane gather + fused decoder MLPs for one wave-tile of 64 points (forward direction).
+//
+// Lane roles inside a wave (lane l = 0..63):
+//   "sample role":  lane l owns point l of the tile (per-point scalars: z, sdf, alpha, ...).
+//   "block role":   the tile is cut into 4 blocks of 16 points; for block b lane l works on point 16b + (l & 15)
+//                   and on the channel octet q = l >> 4 (channels 8q..8q+7 of each 32-channel texel).
+//
+// Gather (block role): per plane and bilinear corner a lane loads its 8 channels as two 16-byte loads, the four
+// q-lanes of a point together cover the texel's 128 contiguous bytes (channels-last planes), so every wave
+// instruction moves 16 full 128-B lines.  The weighted sum stays in registers: feat[level][8].
+//
+// MLP (fp32 MFMA 16x16x4, exact fp32 FMA chains): the layers are evaluated TRANSPOSED,
+//   H1^T[16 x 16pts] = W1[16 x 64] . feat^T[64 x 16pts],
+// so that (i) the gathered registers are the B operand as they stand (B[k][col]: col = l & 15 = point,
+// k-slot = l >> 4 = q) with the K index permuted to  k(ks, q) = level*32 + 8q + i,  ks = level*8 + i,
+// and the A operand W1[j = l & 15][k(ks, q)] is read from LDS in that same permutation; and (ii) each layer's
+// accumulator (rows 4q+reg, col = point) is directly the next layer's B operand with k(ks, q) = 4q + ks.
+// The output layer is zero-padded to 16 rows and block b's copy of it is placed at rows 4b..4b+3, all four blocks
+// accumulating into ONE accumulator: afterwards lane l (sample role!) holds the outputs of point l in acc[0..2].
+// No LDS round trip and no cross-lane shuffle anywhere between the gather and the per-point epilogue.
+#pragma once
+#include "eslam_common.h"
+
+template <bool CL>
+__device__ __forceinline__ void gather8(const eslam_plane_t& P, float u, float v, int q, float acc[8]) {
+    const AxisCoord ax = axis_coord(u, P.w);
+    const AxisCoord ay = axis_coord(v, P.h);
+    const float w00 = (1.0f - ax.t) * (1.0f - ay.t);
+    const float w01 = ax.t * (1.0f - ay.t);
+    const float w10 = (1.0f - ax.t) * ay.t;
+    const float w11 = ax.t * ay.t;
+    // 32-bit unsigned element offsets from the wave-uniform plane base: lets the loads use the
+    // SGPR-base + VGPR-offset addressing form (one address VGPR per load instead of two)
+    const unsigned sy = (unsigned)P.stride_y, sx = (unsigned)P.stride_x;
+    const unsigned r0 = ay.i0 * sy, r1 = ay.i1 * sy;
+    const unsigned c0 = ax.i0 * sx, c1 = ax.i1 * sx;
+    const float* __restrict__ data = P.data;
+    if (CL) {
+        const unsigned q8 = 8u * q;
+        const unsigned o00 = r0 + c0 + q8, o01 = r0 + c1 + q8, o10 = r1 + c0 + q8, o11 = r1 + c1 + q8;
+        const float4_t a00 = *(const float4_t*)(data + o00), b00 = *(const float4_t*)(data + o00 + 4u);
+        const float4_t a01 = *(const float4_t*)(data + o01), b01 = *(const float4_t*)(data + o01 + 4u);
+        const float4_t a10 = *(const float4_t*)(data + o10), b10 = *(const float4_t*)(data + o10 + 4u);
+        const float4_t a11 = *(const float4_t*)(data + o11), b11 = *(const float4_t*)(data + o11 + 4u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[i] += a00[i] * w00 + a01[i] * w01 + a10[i] * w10 + a11[i] * w11;
+            acc[4 + i] += b00[i] * w00 + b01[i] * w01 + b10[i] * w10 + b11[i] * w11;
+        }
+    } else {
+        const unsigned sc = (unsigned)P.stride_c;
+        const unsigned qo = 8u * q * sc;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned co = qo + i * sc;
+            acc[i] += data[co + r0 + c0] * w00 + data[co + r0 + c1] * w01 + data[co + r1 + c0] * w10 +
+                      data[co + r1 + c1] * w11;
+        }
+    }
+}
+
+// Per-decoder MFMA operand fragments, read from the LDS weight image (eslam_common.h layout).
+struct DecFrag {
+    float w1[16];     // W1[r][lvl*32 + 8q + i], index lvl*8 + i
+    float4_t w2;      // W2[r][4q .. 4q+3]
+    float4_t w3;      // W3pad[r & 3][4q .. 4q+3]
+    float4_t b1, b2;  // b[4q .. 4q+3]
+    float4_t b3;      // b3pad[0..3]
+};
+
+__device__ __forceinline__ void load_dec_frag(DecFrag& f, const float* L, int r, int q) {
+#pragma unroll
+    for (int lvl = 0; lvl < 2; ++lvl) {
+        const float4_t a = *(const float4_t*)(L + DEC_W1 + r * 64 + lvl * 32 + 8 * q);
+        const float4_t b = *(const float4_t*)(L + DEC_W1 + r * 64 + lvl * 32 + 8 * q + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f.w1[lvl * 8 + i] = a[i];
+            f.w1[lvl * 8 + 4 + i] = b[i];
+        }
+    }
+    f.w2 = *(const float4_t*)(L + DEC_W2 + r * 16 + 4 * q);
+    f.w3 = *(const float4_t*)(L + DEC_W3 + (r & 3) * 16 + 4 * q);
+    f.b1 = *(const float4_t*)(L + DEC_B1 + 4 * q);
+    f.b2 = *(const float4_t*)(L + DEC_B2 + 4 * q);
+    f.b3 = *(const float4_t*)(L + DEC_B3);
+}
+
+// hidden activations of one 16-point block: h^T rows 4q+reg, col = point r
+__device__ __forceinline__ void mlp_hidden(const DecFrag& f, const float feat[16], float4_t& h1, float4_t& h2) {
+    float4_t a1 = f.b1;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) a1 = mfma16(f.w1[ks], feat[ks], a1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h1[i] = fmaxf(a1[i], 0.0f);
+    float4_t a2 = f.b2;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) a2 = mfma16(f.w2[ks], h1[ks], a2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h2[i] = fmaxf(a2[i], 0.0f);
+}
+
+// output layer of block b accumulated into the tile-wide accumulator `out` (sample role on return)
+__device__ __forceinline__ void mlp_out_accum(const DecFrag& f, const float4_t& h2, int b, int r, float4_t& out) {
+    const bool mine = (r >> 2) == b;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) out = mfma16(mine ? f.w3[ks] : 0.0f, h2[ks], out);
+}
+
+// Gather the 64 features of decoder `d` (0 geometry planes, 1 colour planes) for the lane's block-role point.
+// `opaque0` is an SGPR holding 0 that the compiler cannot see through (see opaque_zero()): indexing the descriptor
+// table with it keeps the per-plane scalar loads and the values derived from them INSIDE the caller's loop.
+// Without it LICM hoists ~100 loop-invariant scalars of the 12 planes out of the point-block loop, which
+// overflows the SGPR file and ends in VGPR spills to scratch.
+template <bool CL>
+__device__ __forceinline__ void gather_features(const PlaneSet& planes, int d, float x, float y, float z, int q,
+                                                float feat[16], int opaque0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) feat[i] = 0.0f;
+#pragma unroll
+    for (int lvl = 0; lvl < 2; ++lvl) {
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const eslam_plane_t& P = planes.p[2 * (3 * d + o) + lvl + opaque0];
+            gather8<CL>(P, ORIENT_U(o, x, y, z), ORIENT_V(o, x, y, z), q, feat + 8 * lvl);
+            // keep the 8 x 16-B loads of the next plane from being hoisted above this plane's FMAs: with all 48
+            // loads of a block in flight the kernel needs > 256 VGPRs (1 wave / SIMD); per plane it fits in 128.
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// store the lane's 16 gathered features of decoder d for point `pt` into feat_out [N,128]
+__device__ __forceinline__ void store_features(float* feat_out, int64_t pt, int d, int q, const float feat[16]) {
+    float* dst = feat_out + pt * 128 + d * 64 + 8 * q;
+#pragma unroll
+    for (int lvl = 0; lvl < 2; ++lvl) {
+        float4_t a, b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i] = feat[lvl * 8 + i];
+            b[i] = feat[lvl * 8 + 4 + i];
+        }
+        *(float4_t*)(dst + lvl * 32) = a;
+        *(float4_t*)(dst + lvl * 32 + 4) = b;
+    }
+}

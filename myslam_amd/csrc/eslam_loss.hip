@@ -1,0 +1,164 @@
+// Fused caller-side loss (value + upstream gradients).  Restates reference src/Mapper.py:110-144,337-346 and
+// src/Tracker.py:114-148,197-204 without boolean-mask indexing (each of which costs the PyTorch formulation a
+// nonzero() + host sync).  Two launches: (1) per-ray partial sums and set sizes -> 9 global accumulators,
+// (2) gradients scaled by the now-known set sizes, and the loss value.
+#include "eslam_common.h"
+
+// accumulator slots (floats)
+enum { A_N_FRONT = 0, A_N_CENTER, A_N_TAIL, A_S_FRONT, A_S_CENTER, A_S_TAIL, A_N_DEPTH, A_S_DEPTH, A_S_COLOR, A_N_COLOR, A_COUNT };
+
+struct LossW { float fs, center, tail, depth, color; };
+
+// truncation constants as the reference forms them: Python-float products cast to float32 by torch
+struct Trunc { float t, t04; };
+static Trunc make_trunc(double truncation) { return Trunc{(float)truncation, (float)(0.4 * truncation)}; }
+
+__device__ __forceinline__ int sdf_region(float z, float d, Trunc tr) {
+    // Mapper.py:124-134: 0 front, 1 center, 2 tail, 3 back (no loss)
+    const bool front = z < (d - tr.t);
+    const bool back = z > (d + tr.t);
+    const bool center = (z > (d - tr.t04)) && (z < (d + tr.t04));
+    if (front) return 0;
+    if (back) return 3;
+    if (center) return 1;
+    return 2;
+}
+
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ depth, const float* __restrict__ rgb,
+                                                          const float* __restrict__ sdf, const float* __restrict__ z_vals,
+                                                          const float* __restrict__ gt_depth,
+                                                          const float* __restrict__ gt_color,
+                                                          const uint8_t* __restrict__ ray_mask, int R, int S, const Trunc tr,
+                                                          float* __restrict__ acc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ray = blockIdx.x * 4 + wave;
+    float v[A_COUNT];
+#pragma unroll
+    for (int k = 0; k < A_COUNT; ++k) v[k] = 0.0f;
+    if (ray < R) {
+        const float d = gt_depth[ray];
+        const bool m = ray_mask ? (ray_mask[ray] != 0) : (d > 0.0f);
+        const bool mc = ray_mask ? m : true;
+        if (m) {
+            for (int s = lane; s < S; s += WAVE) {
+                const float z = z_vals[(int64_t)ray * S + s];
+                const float sd = sdf[(int64_t)ray * S + s];
+                const int reg = sdf_region(z, d, tr);
+                if (reg == 0) { v[A_N_FRONT] += 1.0f; const float e = sd - 1.0f; v[A_S_FRONT] += e * e; }
+                else if (reg == 1) { v[A_N_CENTER] += 1.0f; const float e = (z + sd * tr.t) - d; v[A_S_CENTER] += e * e; }
+                else if (reg == 2) { v[A_N_TAIL] += 1.0f; const float e = (z + sd * tr.t) - d; v[A_S_TAIL] += e * e; }
+            }
+            if (lane == 0) { const float e = d - depth[ray]; v[A_N_DEPTH] = 1.0f; v[A_S_DEPTH] = e * e; }
+        }
+        if (mc && lane < 3) { const float e = gt_color[3 * ray + lane] - rgb[3 * ray + lane]; v[A_S_COLOR] = e * e; v[A_N_COLOR] = 1.0f; }
+    }
+    __shared__ float red[4][A_COUNT];
+#pragma unroll
+    for (int k = 0; k < A_COUNT; ++k) {
+        const float s = wave_sum(v[k]);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < A_COUNT) {
+        const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (s != 0.0f) atomicAdd(acc + threadIdx.x, s);
+    }
+}
+
+__global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ depth, const float* __restrict__ rgb,
+                                                        const float* __restrict__ sdf, const float* __restrict__ z_vals,
+                                                        const float* __restrict__ gt_depth,
+                                                        const float* __restrict__ gt_color,
+                                                        const uint8_t* __restrict__ ray_mask, int R, int S, const Trunc tr,
+                                                        const LossW w, const float* __restrict__ acc,
+                                                        float* __restrict__ loss, float* __restrict__ g_depth,
+                                                        float* __restrict__ g_rgb, float* __restrict__ g_sdf) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ray = blockIdx.x * 4 + wave;
+    const float nf = acc[A_N_FRONT], nc = acc[A_N_CENTER], nt = acc[A_N_TAIL], nd = acc[A_N_DEPTH], ncol = acc[A_N_COLOR];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // torch.mean over an empty set is NaN (0/0); keep that behaviour
+        loss[0] = w.fs * (acc[A_S_FRONT] / nf) + w.center * (acc[A_S_CENTER] / nc) + w.tail * (acc[A_S_TAIL] / nt) +
+                  w.color * (acc[A_S_COLOR] / ncol) + w.depth * (acc[A_S_DEPTH] / nd);
+    }
+    if (ray >= R) return;
+    const float d = gt_depth[ray];
+    const bool m = ray_mask ? (ray_mask[ray] != 0) : (d > 0.0f);
+    const bool mc = ray_mask ? m : true;
+    const float kf = 2.0f * w.fs / nf, kc = 2.0f * w.center * tr.t / nc, kt = 2.0f * w.tail * tr.t / nt;
+    for (int s = lane; s < S; s += WAVE) {
+        float g = 0.0f;
+        if (m) {
+            const float z = z_vals[(int64_t)ray * S + s];
+            const float sd = sdf[(int64_t)ray * S + s];
+            const int reg = sdf_region(z, d, tr);
+            if (reg == 0) g = kf * (sd - 1.0f);
+            else if (reg == 1) g = kc * ((z + sd * tr.t) - d);
+            else if (reg == 2) g = kt * ((z + sd * tr.t) - d);
+        }
+        g_sdf[(int64_t)ray * S + s] = g;
+    }
+    if (lane == 0) g_depth[ray] = m ? -2.0f * w.depth * (d - depth[ray]) / nd : 0.0f;
+    if (lane < 3) g_rgb[3 * ray + lane] = mc ? -2.0f * w.color * (gt_color[3 * ray + lane] - rgb[3 * ray + lane]) / ncol : 0.0f;
+}
+
+static int loss_args_ok(const char* who, const float* depth, const float* rgb, const float* sdf, const float* z_vals,
+                        const float* gt_depth, const float* gt_color, int R, int S) {
+    if (R <= 0 || S <= 0) {
+        eslam_set_error("%s: empty batch", who);
+        return 0;
+    }
+    if (!depth || !rgb || !sdf || !z_vals || !gt_depth || !gt_color) {
+        eslam_set_error("%s: null argument", who);
+        return 0;
+    }
+    return 1;
+}
+
+extern "C" int eslam_loss_reduce(const float* depth, const float* rgb, const float* sdf, const float* z_vals,
+                                 const float* gt_depth, const float* gt_color, int R, int S, double truncation,
+                                 const uint8_t* ray_mask, float* acc, eslam_stream_t stream) {
+    if (!loss_args_ok("eslam_loss_reduce", depth, rgb, sdf, z_vals, gt_depth, gt_color, R, S)) return 1;
+    if (!acc) {
+        eslam_set_error("eslam_loss_reduce: null accumulator");
+        return 1;
+    }
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, depth, rgb, sdf, z_vals,
+                       gt_depth, gt_color, ray_mask, R, S, make_trunc(truncation), acc);
+    return eslam_check_launch("loss_reduce_kernel");
+}
+
+extern "C" int eslam_loss_grad(const float* depth, const float* rgb, const float* sdf, const float* z_vals,
+                               const float* gt_depth, const float* gt_color, int R, int S, double truncation,
+                               const float* weights5_host, const uint8_t* ray_mask, const float* acc, float* loss,
+                               float* g_depth, float* g_rgb, float* g_sdf, eslam_stream_t stream) {
+    if (!loss_args_ok("eslam_loss_grad", depth, rgb, sdf, z_vals, gt_depth, gt_color, R, S)) return 1;
+    if (!weights5_host || !acc || !loss || !g_depth || !g_rgb || !g_sdf) {
+        eslam_set_error("eslam_loss_grad: null argument");
+        return 1;
+    }
+    const LossW w = {weights5_host[0], weights5_host[1], weights5_host[2], weights5_host[3], weights5_host[4]};
+    hipLaunchKernelGGL(loss_grad_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, depth, rgb, sdf, z_vals,
+                       gt_depth, gt_color, ray_mask, R, S, make_trunc(truncation), w, acc, loss, g_depth, g_rgb, g_sdf);
+    return eslam_check_launch("loss_grad_kernel");
+}
+
+extern "C" int eslam_mapping_loss(const float* depth, const float* rgb, const float* sdf, const float* z_vals,
+                                  const float* gt_depth, const float* gt_color, int R, int S, double truncation,
+                                  const float* weights5_host, int unused_flags, const uint8_t* ray_mask, float* loss,
+                                  float* g_depth, float* g_rgb, float* g_sdf, void* scratch, eslam_stream_t stream) {
+    (void)unused_flags;
+    if (!scratch) {
+        eslam_set_error("eslam_mapping_loss: null scratch");
+        return 1;
+    }
+    if (hipMemsetAsync(scratch, 0, 64, (hipStream_t)stream) != hipSuccess) {
+        eslam_set_error("eslam_mapping_loss: memset failed");
+        return 2;
+    }
+    if (int rc = eslam_loss_reduce(depth, rgb, sdf, z_vals, gt_depth, gt_color, R, S, truncation, ray_mask,
+                                   (float*)scratch, stream))
+        return rc;
+    return eslam_loss_grad(depth, rgb, sdf, z_vals, gt_depth, gt_color, R, S, truncation, weights5_host, ray_mask,
+                           (const float*)scratch, loss, g_depth, g_rgb, g_sdf, stream);
+}

@@ -1,0 +1,697 @@
+// Backward kernels (K8 of SURVEY.md section 2.1): autograd of composite -> decoders -> tri-plane lookup.
+//
+//   composite_bwd_kernel   per ray : upstream (g_depth, g_rgb, g_sdf) -> pre-activation output grads g_o[N,4], g_beta
+//   mlp_bwd_kernel         per 64-point tile and decoder: recompute hidden layers, back-propagate to the 64
+//                          features (g_feat[N,128]) and to the decoder parameters (per-wave slabs); fp32 MFMA
+//   dec_grad_reduce_kernel slabs -> flat decoder gradient
+//   scatter_kernel         g_feat -> plane gradients: per ray and (decoder, level) one wave walks the samples in
+//                          order, merges consecutive samples that fall into the same texel cell in registers and
+//                          flushes 256-B-shaped float atomics (2 texels x 32 channels per wave instruction)
+//   coord_bwd_kernel       optional: gradient w.r.t. the sample position -> rays_o / rays_d (pose) or points
+#include "eslam_decode_tile.h"
+
+#define SLAB 1364          // floats per decoder per wave slab (rgb decoder needs 1363)
+// offsets inside a per-decoder slab
+#define SL_W1 0
+#define SL_B1 1024
+#define SL_W2 1040
+#define SL_B2 1296
+#define SL_W3 1312         // [nout][16], nout <= 3
+#define SL_B3 1360         // [nout]
+
+// ---------------------------------------------------------------------------------------------------------
+// composite backward: autograd of reference src/utils/Renderer.py:140-153
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ z_vals,
+                                                            const float* __restrict__ sdf_in,
+                                                            const float* __restrict__ raw_rgb,
+                                                            const float* __restrict__ beta_p,
+                                                            const float* __restrict__ g_depth,
+                                                            const float* __restrict__ g_rgb,
+                                                            const float* __restrict__ g_sdf, int R, int S,
+                                                            float* __restrict__ g_o, float* __restrict__ g_beta) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ray = blockIdx.x * 4 + wave;
+    if (ray >= R) return;
+    const float beta = beta_p[0];
+    const float gd = g_depth ? g_depth[ray] : 0.0f;
+    const float gr = g_rgb ? g_rgb[3 * ray + 0] : 0.0f;
+    const float gg = g_rgb ? g_rgb[3 * ray + 1] : 0.0f;
+    const float gb = g_rgb ? g_rgb[3 * ray + 2] : 0.0f;
+    const int64_t base = (int64_t)ray * S;
+    const int nchunk = (S + WAVE - 1) / WAVE;
+
+    // pass A: transmittance product of every chunk
+    float chunk_prod[ESLAM_MAX_SAMPLES / WAVE];
+#pragma unroll
+    for (int c = 0; c < ESLAM_MAX_SAMPLES / WAVE; ++c) {
+        chunk_prod[c] = 1.0f;
+        if (c < nchunk) {
+            const int s = c * WAVE + lane;
+            float fac = 1.0f;
+            if (s < S) {
+                const float sd = sdf_in[base + s];
+                const float alpha = 1.0f - expf(-beta * sigmoidf_(-sd * beta));
+                fac = (1.0f - alpha) + 1e-10f;
+            }
+            chunk_prod[c] = __shfl(wave_incl_prod(fac, lane), 63, WAVE);
+        }
+    }
+    // pass B: chunks in reverse, carrying the suffix sum of gw*w
+    float carry = 0.0f;
+    float gbeta_acc = 0.0f;
+#pragma unroll
+    for (int c = ESLAM_MAX_SAMPLES / WAVE - 1; c >= 0; --c) {
+        if (c < nchunk) {
+            float trans_in = 1.0f;
+#pragma unroll
+            for (int k = 0; k < ESLAM_MAX_SAMPLES / WAVE; ++k)
+                if (k < c) trans_in *= chunk_prod[k];
+            const int s = c * WAVE + lane;
+            const bool valid = s < S;
+            const float sd = valid ? sdf_in[base + s] : 0.0f;
+            const float z = valid ? z_vals[base + s] : 0.0f;
+            float cr = 0.f, cg = 0.f, cb = 0.f;
+            if (valid) {
+                cr = raw_rgb[(base + s) * 3 + 0];
+                cg = raw_rgb[(base + s) * 3 + 1];
+                cb = raw_rgb[(base + s) * 3 + 2];
+            }
+            const float sg = sigmoidf_(-sd * beta);
+            const float e = expf(-beta * sg);
+            const float alpha = valid ? 1.0f - e : 0.0f;
+            const float fac = valid ? (1.0f - alpha) + 1e-10f : 1.0f;
+            const float pin = wave_incl_prod(fac, lane);
+            float pex = __shfl_up(pin, 1, WAVE);
+            if (lane == 0) pex = 1.0f;
+            const float T = trans_in * pex;
+            const float w = alpha * T;
+            const float gw = gd * z + gr * cr + gg * cg + gb * cb;
+            const float v = valid ? gw * w : 0.0f;
+            // exclusive suffix sum_{k>i} gw_k w_k, formed WITHOUT subtracting v_i from an inclusive sum: w decays
+            // geometrically along the ray, so (inclusive - own) would lose the small tail in the rounding of the
+            // dominant own term, and g_alpha is itself a cancelling difference of two terms of the size of gw.
+            float vn = __shfl_down(v, 1, WAVE);
+            if (lane == WAVE - 1) vn = 0.0f;
+            const float after_local = wave_incl_suffix_sum(vn, lane);
+            const float after = after_local + carry;
+            const float g_alpha = gw * T - after / fac;
+            carry += __shfl(after_local, 0, WAVE) + __shfl(v, 0, WAVE);
+            if (valid) {
+                const float ds = sg * (1.0f - sg);                // sigmoid'
+                const float dalpha_dsdf = -beta * beta * e * ds;
+                const float dalpha_dbeta = e * (sg - beta * ds * sd);
+                gbeta_acc += g_alpha * dalpha_dbeta;
+                const float g_sdf_tot = (g_sdf ? g_sdf[base + s] : 0.0f) + g_alpha * dalpha_dsdf;
+                float4_t o;
+                o[0] = w * gr * cr * (1.0f - cr);
+                o[1] = w * gg * cg * (1.0f - cg);
+                o[2] = w * gb * cb * (1.0f - cb);
+                o[3] = g_sdf_tot * (1.0f - sd * sd);
+                *(float4_t*)(g_o + (base + s) * 4) = o;
+            }
+        }
+    }
+    const float tot = wave_sum(gbeta_acc);
+    if (lane == 0 && g_beta) atomicAdd(g_beta, tot);
+}
+
+// decode-mode variant: g_o = g_raw * activation'(raw)      (autograd of decoders.py:103,123)
+__global__ void decode_act_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ g_raw, int64_t N,
+                                      float* __restrict__ g_o) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float4_t v = *(const float4_t*)(raw + 4 * i);
+    const float4_t g = *(const float4_t*)(g_raw + 4 * i);
+    float4_t o;
+    o[0] = g[0] * v[0] * (1.0f - v[0]);
+    o[1] = g[1] * v[1] * (1.0f - v[1]);
+    o[2] = g[2] * v[2] * (1.0f - v[2]);
+    o[3] = g[3] * (1.0f - v[3] * v[3]);
+    *(float4_t*)(g_o + 4 * i) = o;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// decoder MLP backward (autograd of reference src/networks/decoders.py:97-103 / 117-123)
+// ---------------------------------------------------------------------------------------------------------
+#define TP 20                      // row pitch (floats) of the 16x16 transpose tiles: conflict-free, 16-B aligned
+__global__ __launch_bounds__(256) void mlp_bwd_kernel(const eslam_decoders_t dec, const float* __restrict__ feat,
+                                                      const float* __restrict__ g_o, int64_t N,
+                                                      float* __restrict__ g_feat, float* __restrict__ slabs) {
+    __shared__ __attribute__((aligned(16))) float wlds[2 * DEC_LDS];
+    __shared__ __attribute__((aligned(16))) float tiles[4][4][16 * TP];   // per wave: gz1, gz2, h1, h2 (as [pt][j])
+    __shared__ __attribute__((aligned(16))) float gtile[4][64 * 4];       // per wave: g_o of the tile [pt][o]
+    stage_decoder_weights(wlds, dec, threadIdx.x, blockDim.x);
+    __syncthreads();
+
+    const int d = blockIdx.y;                         // 0 = sdf decoder, 1 = colour decoder
+    const int nout = d ? 3 : 1;
+    const float* L = wlds + d * DEC_LDS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    float* tz1 = tiles[wave][0];
+    float* tz2 = tiles[wave][1];
+    float* th1 = tiles[wave][2];
+    float* th2 = tiles[wave][3];
+    float* gt = gtile[wave];
+
+    DecFrag f;
+    load_dec_frag(f, L, r, q);
+    float w3col[4], w2t[4], w1t[4][4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        w3col[ks] = L[DEC_W3 + ks * 16 + r];                    // W3pad[o = ks][j = r]
+        w2t[ks] = L[DEC_W2 + (4 * q + ks) * 16 + r];            // W2[j = 4q+ks][k' = r]
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const int fidx = (mb >> 1) * 32 + 8 * (r >> 2) + 4 * (mb & 1) + (r & 3);
+            w1t[mb][ks] = L[DEC_W1 + (4 * q + ks) * 64 + fidx]; // W1[j = 4q+ks][f(mb, r)]
+        }
+    }
+
+    float4_t gW1[4], gW2, gW3, gb1, gb2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gW1[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    gW2 = gW3 = gb1 = gb2 = (float4_t){0.f, 0.f, 0.f, 0.f};
+    float gb3[3] = {0.f, 0.f, 0.f};
+
+    const int64_t ntiles = (N + 63) / 64;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t p0 = tile * 64;
+        const int nvalid = (int)min((int64_t)64, N - p0);
+        const int nblk = (nvalid + 15) >> 4;
+
+        // sample role: pre-activation output gradients of this decoder
+        float go[4] = {0.f, 0.f, 0.f, 0.f};
+        if (lane < nvalid) {
+            const float4_t g = *(const float4_t*)(g_o + (p0 + lane) * 4);
+            if (d == 0) go[0] = g[3];
+            else { go[0] = g[0]; go[1] = g[1]; go[2] = g[2]; }
+        }
+#pragma unroll
+        for (int o = 0; o < 3; ++o) gb3[o] += go[o];
+        *(float4_t*)(gt + lane * 4) = (float4_t){go[0], go[1], go[2], go[3]};
+
+#pragma unroll 1
+        for (int b = 0; b < nblk; ++b) {
+            // block role: features of point 16b + r (gather layout, 8 channels per level)
+            const int64_t pt = min(p0 + 16 * b + r, N - 1);
+            const float* fp = feat + pt * 128 + d * 64 + 8 * q;
+            float ft[16];
+#pragma unroll
+            for (int lvl = 0; lvl < 2; ++lvl) {
+                const float4_t a = *(const float4_t*)(fp + lvl * 32);
+                const float4_t c = *(const float4_t*)(fp + lvl * 32 + 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { ft[lvl * 8 + i] = a[i]; ft[lvl * 8 + 4 + i] = c[i]; }
+            }
+            float4_t h1, h2;
+            mlp_hidden(f, ft, h1, h2);
+
+            // g_h2^T = W3^T . g_o^T   (K = (block', o); only block' == b contributes)
+            float4_t gh2 = (float4_t){0.f, 0.f, 0.f, 0.f};
+            const bool mine = (q == b);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) gh2 = mfma16(mine ? w3col[ks] : 0.0f, go[ks], gh2);
+            float4_t gz2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gz2[i] = h2[i] > 0.0f ? gh2[i] : 0.0f;
+            // g_h1^T = W2^T . g_z2^T
+            float4_t gh1 = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) gh1 = mfma16(w2t[ks], gz2[ks], gh1);
+            float4_t gz1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gz1[i] = h1[i] > 0.0f ? gh1[i] : 0.0f;
+            gb1 += gz1;
+            gb2 += gz2;
+
+            // g_feat^T = W1^T . g_z1^T, four row blocks permuted so that lane (r,q) receives channels 8q..8q+7
+            float gf[16];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                float4_t acc = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) acc = mfma16(w1t[mb][ks], gz1[ks], acc);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gf[(mb >> 1) * 8 + 4 * (mb & 1) + i] = acc[i];
+            }
+            if (p0 + 16 * b + r < N) store_features(g_feat, p0 + 16 * b + r, d, q, gf);
+
+            // transposes through LDS: D layout (rows 4q+reg, col = point r) -> [point][row]
+            *(float4_t*)(tz1 + r * TP + 4 * q) = gz1;
+            *(float4_t*)(tz2 + r * TP + 4 * q) = gz2;
+            *(float4_t*)(th1 + r * TP + 4 * q) = h1;
+            *(float4_t*)(th2 + r * TP + 4 * q) = h2;
+            WAVE_SYNC();
+
+            // parameter gradients: contraction over the block's 16 points (K = point 4q + ks)
+            float az1[4], az2[4], bh1[4], bh2[4], ago[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int prow = 4 * q + ks;
+                az1[ks] = tz1[prow * TP + r];
+                az2[ks] = tz2[prow * TP + r];
+                bh1[ks] = th1[prow * TP + r];
+                bh2[ks] = th2[prow * TP + r];
+                ago[ks] = (r < 4) ? gt[(16 * b + prow) * 4 + r] : 0.0f;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                gW2 = mfma16(az2[ks], bh1[ks], gW2);              // g_W2[j][k'] : rows j = 4q+reg, col k' = r
+                gW3 = mfma16(ago[ks], bh2[ks], gW3);              // g_W3[o][j]  : rows o = 4q+reg (q = 0), col j = r
+            }
+            // g_W1[j][f]: B = features of point 4q+ks, columns permuted: column c of n-block nb <-> feature 4c + nb
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int64_t pk = min(p0 + 16 * b + 4 * q + ks, N - 1);
+                const float4_t fb = *(const float4_t*)(feat + pk * 128 + d * 64 + 4 * r);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) gW1[nb] = mfma16(az1[ks], fb[nb], gW1[nb]);
+            }
+            WAVE_SYNC();
+        }
+    }
+
+    // per-wave slab: [wave_global][decoder] -> SLAB floats
+    float* sl = slabs + (((int64_t)blockIdx.x * 4 + wave) * 2 + d) * SLAB;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int j = 4 * q + reg;
+        float4_t v;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) v[nb] = gW1[nb][reg];
+        *(float4_t*)(sl + SL_W1 + j * 64 + 4 * r) = v;
+        sl[SL_W2 + j * 16 + r] = gW2[reg];
+        if (q == 0 && reg < nout) sl[SL_W3 + reg * 16 + r] = gW3[reg];
+    }
+    // bias gradients: sum over the 16 point lanes
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        float a = gb1[reg], c = gb2[reg];
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) {
+            a += __shfl_xor(a, m, WAVE);
+            c += __shfl_xor(c, m, WAVE);
+        }
+        if (r == 0) {
+            sl[SL_B1 + 4 * q + reg] = a;
+            sl[SL_B2 + 4 * q + reg] = c;
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        const float t = wave_sum(gb3[o]);
+        if (lane == 0 && o < nout) sl[SL_B3 + o] = t;
+    }
+}
+
+// slabs [nrows][2][SLAB] -> g_dec (flat, order of eslam_decoders_t).  grid (ceil(SLAB/64), 2), block 256.
+__global__ __launch_bounds__(256) void dec_grad_reduce_kernel(const float* __restrict__ slabs, int nrows,
+                                                              float* __restrict__ g_dec) {
+    __shared__ float red[4][64];
+    const int d = blockIdx.y;
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;
+    float acc = 0.0f;
+    if (col < SLAB)
+        for (int row = part; row < nrows; row += 4) acc += slabs[((int64_t)row * 2 + d) * SLAB + col];
+    red[part][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (part == 0 && col < SLAB) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        const int nout = d ? 3 : 1;
+        // slab offset -> flat offset inside the decoder's parameter block
+        int dst = -1;
+        if (col < SL_W3) dst = col;                                   // W1,b1,W2,b2 are laid out identically
+        else if (col < SL_W3 + nout * 16) dst = 1312 + (col - SL_W3);
+        else if (col >= SL_B3 && col < SL_B3 + nout) dst = 1312 + nout * 16 + (col - SL_B3);
+        if (dst >= 0) g_dec[(d ? 1329 : 0) + dst] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// scatter of feature gradients into the plane gradients (autograd of decoders.py:79-82, i.e. of the 12 grid_sample)
+// ---------------------------------------------------------------------------------------------------------
+// One wave = one ray x one (decoder, level): the three orientations of that level share the 32 gradient channels.
+// Lane (hx = l >> 5, c = l & 31): hx selects the x-corner (x0 / x1), c the channel.  Samples are visited in z
+// order; while consecutive samples stay in the same bilinear cell of a plane their contributions are summed in two
+// registers (row y0, row y1) and written with one pair of atomic instructions when the cell changes.
+template <bool RENDER>
+__global__ __launch_bounds__(256) void scatter_kernel(const PlaneSet planes, const Bound bnd,
+                                                      const float* __restrict__ rays_o,
+                                                      const float* __restrict__ rays_d,
+                                                      const float* __restrict__ z_vals,   // RENDER: [R,S]; else pts [N,3]
+                                                      int R, int S, const float* __restrict__ g_feat) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ray = blockIdx.x;
+    const int d = wave >> 1, lvl = wave & 1;
+    const int hx = lane >> 5, c = lane & 31;
+    float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+    if (RENDER) {
+        ox = rays_o[ray * 3 + 0]; oy = rays_o[ray * 3 + 1]; oz = rays_o[ray * 3 + 2];
+        dx = rays_d[ray * 3 + 0]; dy = rays_d[ray * 3 + 1]; dz = rays_d[ray * 3 + 2];
+    }
+    const int64_t base = (int64_t)ray * S;
+    const int64_t npts = RENDER ? (int64_t)R * S : (int64_t)R;     // decode mode: R = N points, S = 64 per "ray"
+    const int scount = RENDER ? S : (int)min((int64_t)S, npts - base);
+
+    // run state per orientation
+    int cur0[3], cur1[3], curdx[3];
+    float acc0[3], acc1[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) { cur0[o] = -1; cur1[o] = -1; curdx[o] = 0; acc0[o] = 0.f; acc1[o] = 0.f; }
+
+    for (int c0 = 0; c0 < scount; c0 += WAVE) {
+        const int nvalid = min(WAVE, scount - c0);
+        // sample role: cell coordinates of point c0 + lane in the three planes of this (decoder, level)
+        float x, y, z;
+        {
+            const int s = min(c0 + lane, scount - 1);
+            if (RENDER) {
+                const float zz = z_vals[base + s];
+                x = ox + dx * zz; y = oy + dy * zz; z = oz + dz * zz;
+            } else {
+                x = z_vals[(base + s) * 3 + 0]; y = z_vals[(base + s) * 3 + 1]; z = z_vals[(base + s) * 3 + 2];
+            }
+            x = norm_coord(x, bnd.lo[0], bnd.hi[0]);
+            y = norm_coord(y, bnd.lo[1], bnd.hi[1]);
+            z = norm_coord(z, bnd.lo[2], bnd.hi[2]);
+        }
+        int off0[3], off1[3], offdx[3];
+        float tx[3], ty[3];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const eslam_plane_t& P = planes.p[2 * (3 * d + o) + lvl];
+            const AxisCoord ax = axis_coord(ORIENT_U(o, x, y, z), P.w);
+            const AxisCoord ay = axis_coord(ORIENT_V(o, x, y, z), P.h);
+            off0[o] = ay.i0 * (int)P.stride_y + ax.i0 * (int)P.stride_x;
+            off1[o] = ay.i1 * (int)P.stride_y + ax.i0 * (int)P.stride_x;
+            offdx[o] = (ax.i1 - ax.i0) * (int)P.stride_x;
+            tx[o] = ax.t;
+            ty[o] = ay.t;
+        }
+        for (int i = 0; i < nvalid; ++i) {
+            const float g = g_feat[(base + c0 + i) * 128 + d * 64 + lvl * 32 + c];
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                const eslam_plane_t& P = planes.p[2 * (3 * d + o) + lvl];
+                const int n0 = __builtin_amdgcn_readlane(off0[o], i);
+                const int n1 = __builtin_amdgcn_readlane(off1[o], i);
+                const int ndx = __builtin_amdgcn_readlane(offdx[o], i);
+                const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tx[o]), i));
+                const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ty[o]), i));
+                if (n0 != cur0[o] || n1 != cur1[o] || ndx != curdx[o]) {     // wave-uniform
+                    if (cur0[o] >= 0) {
+                        float* gp = P.grad + hx * curdx[o] + c * (int)P.stride_c;
+                        atomicAdd(gp + cur0[o], acc0[o]);
+                        atomicAdd(gp + cur1[o], acc1[o]);
+                    }
+                    cur0[o] = n0; cur1[o] = n1; curdx[o] = ndx;
+                    acc0[o] = 0.f; acc1[o] = 0.f;
+                }
+                const float wx = hx ? sx : 1.0f - sx;
+                acc0[o] += g * (wx * (1.0f - sy));
+                acc1[o] += g * (wx * sy);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        if (cur0[o] >= 0) {
+            const eslam_plane_t& P = planes.p[2 * (3 * d + o) + lvl];
+            float* gp = P.grad + hx * curdx[o] + c * (int)P.stride_c;
+            atomicAdd(gp + cur0[o], acc0[o]);
+            atomicAdd(gp + cur1[o], acc1[o]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// gradient w.r.t. sample positions (autograd of the grid coordinates + common.py:215-217 + Renderer.py:136-137)
+// ---------------------------------------------------------------------------------------------------------
+template <bool CL>
+__device__ __forceinline__ void coord_grad8(const eslam_plane_t& P, float u, float v, int q, const float g[8],
+                                            float& gu, float& gv) {
+    const AxisCoord ax = axis_coord(u, P.w);
+    const AxisCoord ay = axis_coord(v, P.h);
+    const int sy = (int)P.stride_y, sx = (int)P.stride_x, sc = (int)P.stride_c;
+    const int r0 = ay.i0 * sy, r1 = ay.i1 * sy, c0 = ax.i0 * sx, c1 = ax.i1 * sx;
+    float su = 0.f, sv = 0.f;
+    const float* base = P.data + 8 * q * sc;
+    if (CL) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const float4_t t00 = *(const float4_t*)(base + r0 + c0 + 4 * hh);
+            const float4_t t01 = *(const float4_t*)(base + r0 + c1 + 4 * hh);
+            const float4_t t10 = *(const float4_t*)(base + r1 + c0 + 4 * hh);
+            const float4_t t11 = *(const float4_t*)(base + r1 + c1 + 4 * hh);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                su += g[4 * hh + i] * ((t01[i] - t00[i]) * (1.0f - ay.t) + (t11[i] - t10[i]) * ay.t);
+                sv += g[4 * hh + i] * ((t10[i] - t00[i]) * (1.0f - ax.t) + (t11[i] - t01[i]) * ax.t);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float* b = base + i * sc;
+            const float t00 = b[r0 + c0], t01 = b[r0 + c1], t10 = b[r1 + c0], t11 = b[r1 + c1];
+            su += g[i] * ((t01 - t00) * (1.0f - ay.t) + (t11 - t10) * ay.t);
+            sv += g[i] * ((t10 - t00) * (1.0f - ax.t) + (t11 - t01) * ax.t);
+        }
+    }
+    // d(ix)/du = (w-1)/2 strictly inside, 0 where the border clamp is active (ATen clip_coordinates_set_grad)
+    gu += ax.inside ? su * (0.5f * (float)(P.w - 1)) : 0.0f;
+    gv += ay.inside ? sv * (0.5f * (float)(P.h - 1)) : 0.0f;
+}
+
+template <bool CL, bool RENDER>
+__global__ __launch_bounds__(256, 4) void coord_bwd_kernel(const PlaneSet planes, const Bound bnd,
+                                                        const float* __restrict__ rays_o,
+                                                        const float* __restrict__ rays_d,
+                                                        const float* __restrict__ z_vals, int R, int S,
+                                                        const float* __restrict__ g_feat,
+                                                        float* __restrict__ g_rays_o, float* __restrict__ g_rays_d) {
+    // RENDER: one wave per ray, outputs g_rays_o/g_rays_d [R,3].
+    // else:   one wave per 64 points (z_vals = pts [N,3], R = N), output g_rays_o = g_pts [N,3].
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t nunits = RENDER ? R : ((int64_t)R + 63) / 64;
+    if (unit >= nunits) return;
+    float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+    if (RENDER) {
+        ox = rays_o[unit * 3 + 0]; oy = rays_o[unit * 3 + 1]; oz = rays_o[unit * 3 + 2];
+        dx = rays_d[unit * 3 + 0]; dy = rays_d[unit * 3 + 1]; dz = rays_d[unit * 3 + 2];
+    }
+    const int64_t base = RENDER ? unit * S : unit * 64;
+    const int scount = RENDER ? S : (int)min((int64_t)64, (int64_t)R - base);
+    const float sc3[3] = {2.0f / (bnd.hi[0] - bnd.lo[0]), 2.0f / (bnd.hi[1] - bnd.lo[1]), 2.0f / (bnd.hi[2] - bnd.lo[2])};
+    float go_acc[3] = {0.f, 0.f, 0.f}, gd_acc[3] = {0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < scount; s0 += 16) {
+        const int s = s0 + r;
+        const bool valid = s < scount;
+        const int sc_ = min(s, scount - 1);
+        float x, y, z, zz = 0.f;
+        if (RENDER) {
+            zz = z_vals[base + sc_];
+            x = ox + dx * zz; y = oy + dy * zz; z = oz + dz * zz;
+        } else {
+            x = z_vals[(base + sc_) * 3 + 0]; y = z_vals[(base + sc_) * 3 + 1]; z = z_vals[(base + sc_) * 3 + 2];
+        }
+        x = norm_coord(x, bnd.lo[0], bnd.hi[0]);
+        y = norm_coord(y, bnd.lo[1], bnd.hi[1]);
+        z = norm_coord(z, bnd.lo[2], bnd.hi[2]);
+        float gp[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+#pragma unroll
+            for (int lvl = 0; lvl < 2; ++lvl) {
+                const float* gfp = g_feat + (base + sc_) * 128 + d * 64 + lvl * 32 + 8 * q;
+                const float4_t ga = *(const float4_t*)gfp, gb = *(const float4_t*)(gfp + 4);
+                const float g[8] = {ga[0], ga[1], ga[2], ga[3], gb[0], gb[1], gb[2], gb[3]};
+#pragma unroll
+                for (int o = 0; o < 3; ++o) {
+                    const eslam_plane_t& P = planes.p[2 * (3 * d + o) + lvl];
+                    float gu = 0.f, gv = 0.f;
+                    coord_grad8<CL>(P, ORIENT_U(o, x, y, z), ORIENT_V(o, x, y, z), q, g, gu, gv);
+                    __builtin_amdgcn_sched_barrier(0);
+                    gp[o == 2 ? 1 : 0] += gu;      // first coordinate: x (xy, xz) or y (yz)
+                    gp[o == 0 ? 1 : 2] += gv;      // second coordinate: y (xy) or z (xz, yz)
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float v = gp[k];
+            v += __shfl_xor(v, 16, WAVE);           // sum the four channel octets
+            v += __shfl_xor(v, 32, WAVE);
+            v = valid ? v * sc3[k] : 0.0f;
+            if (RENDER) {
+                if (q == 0) { go_acc[k] += v; gd_acc[k] += v * zz; }
+            } else if (q == 0 && valid) {
+                g_rays_o[(base + s) * 3 + k] = v;
+            }
+        }
+    }
+    if (RENDER) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float a = wave_sum(go_acc[k]);
+            const float b = wave_sum(gd_acc[k]);
+            if (lane == 0) {
+                g_rays_o[unit * 3 + k] = a;
+                g_rays_d[unit * 3 + k] = b;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+bool eslam_planes_channels_last(const eslam_plane_t* planes, int first, int count);
+int eslam_validate_planes(const eslam_plane_t* planes, int first, int count);
+
+static Bound make_bound(const float* b6) {
+    Bound b;
+    for (int k = 0; k < 3; ++k) {
+        b.lo[k] = b6[2 * k];
+        b.hi[k] = b6[2 * k + 1];
+        b.inv_len_unused[k] = 0.f;
+    }
+    return b;
+}
+
+#define MLP_BWD_MAX_WG 512
+
+static int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
+
+// workspace layout: g_o [n,4] | g_feat [n,128] | slabs [MLP_BWD_MAX_WG*4][2][SLAB]
+extern "C" int64_t eslam_bwd_workspace_bytes(int64_t n_points) {
+    if (n_points < 0) return -1;
+    return align256(n_points * 4 * 4) + align256(n_points * 128 * 4) +
+           align256((int64_t)MLP_BWD_MAX_WG * 4 * 2 * SLAB * 4);
+}
+
+static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, const Bound& bnd, const float* rays_o,
+                      const float* rays_d, const float* z_or_pts, int64_t R, int S, bool render, const float* feat,
+                      float* g_o, float* g_feat, float* slabs, float* g_dec, float* g_out_a, float* g_out_b,
+                      hipStream_t st) {
+    const int64_t N = render ? R * S : R;
+    PlaneSet ps;
+    for (int i = 0; i < NPL; ++i) ps.p[i] = planes[i];
+    const bool cl = eslam_planes_channels_last(planes, 0, NPL);
+
+    // decoder MLP backward
+    const int64_t ntiles = (N + 63) / 64;
+    const int nwg = (int)((ntiles + 3) / 4 < MLP_BWD_MAX_WG ? (ntiles + 3) / 4 : MLP_BWD_MAX_WG);
+    hipLaunchKernelGGL(mlp_bwd_kernel, dim3(nwg, 2), dim3(256), 0, st, *dec, feat, g_o, N, g_feat, slabs);
+    if (int rc = eslam_check_launch("mlp_bwd_kernel")) return rc;
+    hipLaunchKernelGGL(dec_grad_reduce_kernel, dim3((SLAB + 63) / 64, 2), dim3(256), 0, st, slabs, nwg * 4, g_dec);
+    if (int rc = eslam_check_launch("dec_grad_reduce_kernel")) return rc;
+
+    // plane gradients
+    bool any_grad = false, all_grad = true;
+    for (int i = 0; i < NPL; ++i) {
+        any_grad |= planes[i].grad != nullptr;
+        all_grad &= planes[i].grad != nullptr;
+    }
+    if (any_grad && !all_grad) {
+        eslam_set_error("plane gradients must be requested for all 12 planes or for none");
+        return 1;
+    }
+    if (any_grad) {
+        if (render)
+            hipLaunchKernelGGL((scatter_kernel<true>), dim3((unsigned)R), dim3(256), 0, st, ps, bnd, rays_o, rays_d,
+                               z_or_pts, (int)R, S, g_feat);
+        else
+            hipLaunchKernelGGL((scatter_kernel<false>), dim3((unsigned)ntiles), dim3(256), 0, st, ps, bnd, rays_o,
+                               rays_d, z_or_pts, (int)R, 64, g_feat);
+        if (int rc = eslam_check_launch("scatter_kernel")) return rc;
+    }
+    // position gradients
+    if (g_out_a) {
+        const int64_t nunits = render ? R : ntiles;
+        dim3 grid((unsigned)((nunits + 3) / 4)), block(256);
+#define LAUNCH(CLv, RD)                                                                                            \
+    hipLaunchKernelGGL((coord_bwd_kernel<CLv, RD>), grid, block, 0, st, ps, bnd, rays_o, rays_d, z_or_pts, (int)R, \
+                       S, g_feat, g_out_a, g_out_b)
+        if (cl && render) LAUNCH(true, true);
+        else if (cl) LAUNCH(true, false);
+        else if (render) LAUNCH(false, true);
+        else LAUNCH(false, false);
+#undef LAUNCH
+        if (int rc = eslam_check_launch("coord_bwd_kernel")) return rc;
+    }
+    return 0;
+}
+
+extern "C" int eslam_render_bwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
+                                const float* rays_o, const float* rays_d, const float* z_vals, int R, int S,
+                                const float* sdf, const float* raw_rgb, const float* feat, const float* g_depth,
+                                const float* g_rgb, const float* g_sdf, float* g_dec, float* g_beta, float* g_rays_o,
+                                float* g_rays_d, void* workspace, eslam_stream_t stream) {
+    if (R <= 0) return 0;
+    if (S <= 0 || S > ESLAM_MAX_SAMPLES) {
+        eslam_set_error("eslam_render_bwd: S=%d outside [1,%d]", S, ESLAM_MAX_SAMPLES);
+        return 1;
+    }
+    if (!planes || !dec || !bound6_host || !rays_o || !rays_d || !z_vals || !sdf || !raw_rgb || !feat || !g_dec ||
+        !g_beta || !workspace) {
+        eslam_set_error("eslam_render_bwd: null argument");
+        return 1;
+    }
+    if ((g_rays_o == nullptr) != (g_rays_d == nullptr)) {
+        eslam_set_error("eslam_render_bwd: g_rays_o and g_rays_d must both be given or both be NULL");
+        return 1;
+    }
+    if ((int64_t)R * S * 128 >= ((int64_t)1 << 40)) {
+        eslam_set_error("eslam_render_bwd: batch too large");
+        return 1;
+    }
+    if (eslam_validate_planes(planes, 0, NPL)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t N = (int64_t)R * S;
+    char* ws = (char*)workspace;
+    float* g_o = (float*)ws;
+    float* g_feat = (float*)(ws + align256(N * 16));
+    float* slabs = (float*)(ws + align256(N * 16) + align256(N * 512));
+    const Bound bnd = make_bound(bound6_host);
+
+    if (hipMemsetAsync(g_beta, 0, sizeof(float), st) != hipSuccess) {
+        eslam_set_error("eslam_render_bwd: memset failed");
+        return 2;
+    }
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, st, z_vals, sdf, raw_rgb, dec->beta,
+                       g_depth, g_rgb, g_sdf, R, S, g_o, g_beta);
+    if (int rc = eslam_check_launch("composite_bwd_kernel")) return rc;
+    return bwd_common(planes, dec, bnd, rays_o, rays_d, z_vals, R, S, true, feat, g_o, g_feat, slabs, g_dec, g_rays_o,
+                      g_rays_d, st);
+}
+
+extern "C" int eslam_decode_bwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
+                                const float* pts, int64_t N, const float* raw, const float* feat, const float* g_raw,
+                                float* g_dec, float* g_pts, void* workspace, eslam_stream_t stream) {
+    if (N <= 0) return 0;
+    if (!planes || !dec || !bound6_host || !pts || !raw || !feat || !g_raw || !g_dec || !workspace) {
+        eslam_set_error("eslam_decode_bwd: null argument");
+        return 1;
+    }
+    if (N >= ((int64_t)1 << 31)) {
+        eslam_set_error("eslam_decode_bwd: N too large");
+        return 1;
+    }
+    if (eslam_validate_planes(planes, 0, NPL)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    float* g_o = (float*)ws;
+    float* g_feat = (float*)(ws + align256(N * 16));
+    float* slabs = (float*)(ws + align256(N * 16) + align256(N * 512));
+    const Bound bnd = make_bound(bound6_host);
+    hipLaunchKernelGGL(decode_act_bwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, raw, g_raw, N, g_o);
+    if (int rc = eslam_check_launch("decode_act_bwd_kernel")) return rc;
+    return bwd_common(planes, dec, bnd, nullptr, nullptr, pts, N, 64, false, feat, g_o, g_feat, slabs, g_dec, g_pts,
+                      nullptr, st);
+}

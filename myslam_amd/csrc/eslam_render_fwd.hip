@@ -1,0 +1,251 @@
+// Forward kernels: fused tri-plane gather -> SDF/colour MLPs -> volumetric composite (render), and the
+// decoder-only variant on free points (Decoders.forward / get_raw_sdf).
+//
+// One wave64 = one ray (render) or one tile of 64 points (decode); 4 waves per workgroup share an LDS copy of
+// the decoder weights.  See eslam_decode_tile.h for the lane roles and the MFMA operand plan.
+#include "eslam_decode_tile.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// render: replaces reference src/utils/Renderer.py:136-147 (+ decoders.py:64-146, common.py:204-218)
+// ---------------------------------------------------------------------------------------------------------
+template <bool CL, bool SAVE>
+__global__ __launch_bounds__(256, 4) void render_fwd_kernel(const PlaneSet planes, const eslam_decoders_t dec,
+                                                         const Bound bnd, const float* __restrict__ rays_o,
+                                                         const float* __restrict__ rays_d,
+                                                         const float* __restrict__ z_vals, int R, int S,
+                                                         float* __restrict__ depth_out, float* __restrict__ rgb_out,
+                                                         float* __restrict__ sdf_out, float* __restrict__ raw_rgb_out,
+                                                         float* __restrict__ feat_out) {
+    __shared__ __attribute__((aligned(16))) float wlds[2 * DEC_LDS];
+    stage_decoder_weights(wlds, dec, threadIdx.x, blockDim.x);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int ray = blockIdx.x * 4 + wave;
+    if (ray >= R) return;
+
+    const float ox = rays_o[ray * 3 + 0], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
+    const float dx = rays_d[ray * 3 + 0], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
+    const float beta = dec.beta[0];
+    const float* zrow = z_vals + (int64_t)ray * S;
+
+    float trans_in = 1.0f;                 // transmittance entering the chunk
+    float acc_depth = 0.0f, acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f;
+
+    for (int c0 = 0; c0 < S; c0 += WAVE) {
+        const int nvalid = min(WAVE, S - c0);
+        const int nblk = (nvalid + 15) >> 4;
+
+        float4_t out[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            out[d] = *(const float4_t*)(wlds + d * DEC_LDS + DEC_B3);
+#pragma unroll 1
+            for (int b = 0; b < nblk; ++b) {
+                const int oz0 = opaque_zero(b);
+                // block role: normalised coordinates of point 16b + r
+                const int sb = c0 + 16 * b + r;
+                const float zb = zrow[min(sb, S - 1)];
+                const float px = norm_coord(ox + dx * zb, bnd.lo[0], bnd.hi[0]);
+                const float py = norm_coord(oy + dy * zb, bnd.lo[1], bnd.hi[1]);
+                const float pz = norm_coord(oz + dz * zb, bnd.lo[2], bnd.hi[2]);
+                float feat[16];
+                gather_features<CL>(planes, d, px, py, pz, q, feat, oz0);
+                if (SAVE) {
+                    if (sb < S) store_features(feat_out, (int64_t)ray * S + sb, d, q, feat);
+                }
+                // operand fragments are re-read from LDS per block (9 ds_read_b128) instead of being kept live across
+                // the gather, where they would push the kernel past 128 VGPRs
+                DecFrag f;
+                load_dec_frag(f, wlds + d * DEC_LDS + oz0, r, q);
+                float4_t h1, h2;
+                mlp_hidden(f, feat, h1, h2);
+                mlp_out_accum(f, h2, b, r, out[d]);
+            }
+        }
+
+        // ---- sample role: activations, alpha, transmittance scan, composite (Renderer.py:140-153) ----
+        const bool valid = lane < nvalid;
+        const int s = c0 + lane;
+        const float z = valid ? zrow[s] : 0.0f;
+        const float sdf = tanhf(out[0][0]);
+        const float cr = sigmoidf_(out[1][0]), cg = sigmoidf_(out[1][1]), cb = sigmoidf_(out[1][2]);
+        if (valid) {
+            sdf_out[(int64_t)ray * S + s] = sdf;
+            if (SAVE) {
+                float* rr = raw_rgb_out + ((int64_t)ray * S + s) * 3;
+                rr[0] = cr; rr[1] = cg; rr[2] = cb;
+            }
+        }
+        const float sg = sigmoidf_(-sdf * beta);
+        float alpha = 1.0f - expf(-beta * sg);
+        if (!valid) alpha = 0.0f;
+        const float fac = valid ? (1.0f - alpha) + 1e-10f : 1.0f;
+        const float pin = wave_incl_prod(fac, lane);
+        float pex = __shfl_up(pin, 1, WAVE);
+        if (lane == 0) pex = 1.0f;
+        const float w = alpha * (trans_in * pex);
+        acc_depth += wave_sum(w * z);
+        acc_r += wave_sum(w * cr);
+        acc_g += wave_sum(w * cg);
+        acc_b += wave_sum(w * cb);
+        trans_in *= __shfl(pin, 63, WAVE);
+    }
+    if (lane == 0) {
+        depth_out[ray] = acc_depth;
+        rgb_out[ray * 3 + 0] = acc_r;
+        rgb_out[ray * 3 + 1] = acc_g;
+        rgb_out[ray * 3 + 2] = acc_b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// decode on free points: replaces reference src/networks/decoders.py:127-146 (and :87-105 when SDF_ONLY)
+// ---------------------------------------------------------------------------------------------------------
+template <bool CL, bool SDF_ONLY, bool SAVE>
+__global__ __launch_bounds__(256, 4) void decode_fwd_kernel(const PlaneSet planes, const eslam_decoders_t dec,
+                                                         const Bound bnd, const float* __restrict__ pts, int64_t N,
+                                                         float* __restrict__ raw, float* __restrict__ feat_out) {
+    __shared__ __attribute__((aligned(16))) float wlds[2 * DEC_LDS];
+    stage_decoder_weights(wlds, dec, threadIdx.x, blockDim.x);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int64_t ntiles = (N + 63) / 64;
+
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t p0 = tile * 64;
+        const int nvalid = (int)min((int64_t)64, N - p0);
+        const int nblk = (nvalid + 15) >> 4;
+        float4_t out[2];
+#pragma unroll
+        for (int d = 0; d < (SDF_ONLY ? 1 : 2); ++d) {
+            out[d] = *(const float4_t*)(wlds + d * DEC_LDS + DEC_B3);
+#pragma unroll 1
+            for (int b = 0; b < nblk; ++b) {
+                const int oz0 = opaque_zero(b);
+                const int64_t pb = p0 + 16 * b + r;
+                const int64_t pc = min(pb, N - 1);
+                const float px = norm_coord(pts[pc * 3 + 0], bnd.lo[0], bnd.hi[0]);
+                const float py = norm_coord(pts[pc * 3 + 1], bnd.lo[1], bnd.hi[1]);
+                const float pz = norm_coord(pts[pc * 3 + 2], bnd.lo[2], bnd.hi[2]);
+                float feat[16];
+                gather_features<CL>(planes, d, px, py, pz, q, feat, oz0);
+                if (SAVE) {
+                    if (pb < N) store_features(feat_out, pb, d, q, feat);
+                }
+                DecFrag f;
+                load_dec_frag(f, wlds + d * DEC_LDS + oz0, r, q);
+                float4_t h1, h2;
+                mlp_hidden(f, feat, h1, h2);
+                mlp_out_accum(f, h2, b, r, out[d]);
+            }
+        }
+        if (lane < nvalid) {
+            const float sdf = tanhf(out[0][0]);
+            if (SDF_ONLY) {
+                raw[p0 + lane] = sdf;
+            } else {
+                float4_t v;
+                v[0] = sigmoidf_(out[1][0]);
+                v[1] = sigmoidf_(out[1][1]);
+                v[2] = sigmoidf_(out[1][2]);
+                v[3] = sdf;
+                *(float4_t*)(raw + (p0 + lane) * 4) = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+bool eslam_planes_channels_last(const eslam_plane_t* planes, int first, int count);
+int eslam_validate_planes(const eslam_plane_t* planes, int first, int count);
+
+static Bound make_bound(const float* b6) {
+    Bound b;
+    for (int k = 0; k < 3; ++k) {
+        b.lo[k] = b6[2 * k];
+        b.hi[k] = b6[2 * k + 1];
+        b.inv_len_unused[k] = 0.f;
+    }
+    return b;
+}
+
+extern "C" int eslam_render_fwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
+                                const float* rays_o, const float* rays_d, const float* z_vals, int R, int S,
+                                float* depth, float* rgb, float* sdf, float* raw_rgb, float* feat,
+                                eslam_stream_t stream) {
+    if (R <= 0) return 0;
+    if (S <= 0 || S > ESLAM_MAX_SAMPLES) {
+        eslam_set_error("eslam_render_fwd: S=%d outside [1,%d]", S, ESLAM_MAX_SAMPLES);
+        return 1;
+    }
+    if (!planes || !dec || !bound6_host || !rays_o || !rays_d || !z_vals || !depth || !rgb || !sdf) {
+        eslam_set_error("eslam_render_fwd: null argument");
+        return 1;
+    }
+    if ((raw_rgb == nullptr) != (feat == nullptr)) {
+        eslam_set_error("eslam_render_fwd: raw_rgb and feat must both be given or both be NULL");
+        return 1;
+    }
+    if (eslam_validate_planes(planes, 0, NPL)) return 1;
+    PlaneSet ps;
+    for (int i = 0; i < NPL; ++i) ps.p[i] = planes[i];
+    const Bound bnd = make_bound(bound6_host);
+    const bool cl = eslam_planes_channels_last(planes, 0, NPL);
+    const bool save = feat != nullptr;
+    dim3 grid((R + 3) / 4), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(CLv, SV)                                                                                             \
+    hipLaunchKernelGGL((render_fwd_kernel<CLv, SV>), grid, block, 0, st, ps, *dec, bnd, rays_o, rays_d, z_vals, R, \
+                       S, depth, rgb, sdf, raw_rgb, feat)
+    if (cl && save) LAUNCH(true, true);
+    else if (cl) LAUNCH(true, false);
+    else if (save) LAUNCH(false, true);
+    else LAUNCH(false, false);
+#undef LAUNCH
+    return eslam_check_launch("render_fwd_kernel");
+}
+
+extern "C" int eslam_decode_fwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
+                                const float* pts, int64_t N, int sdf_only, float* raw, float* feat,
+                                eslam_stream_t stream) {
+    if (N <= 0) return 0;
+    if (!planes || !dec || !bound6_host || !pts || !raw) {
+        eslam_set_error("eslam_decode_fwd: null argument");
+        return 1;
+    }
+    if (sdf_only && feat) {
+        eslam_set_error("eslam_decode_fwd: feat cannot be saved in sdf_only mode");
+        return 1;
+    }
+    if (eslam_validate_planes(planes, 0, sdf_only ? 6 : NPL)) return 1;
+    PlaneSet ps;
+    for (int i = 0; i < NPL; ++i) ps.p[i] = planes[sdf_only && i >= 6 ? i - 6 : i];
+    const Bound bnd = make_bound(bound6_host);
+    const bool cl = eslam_planes_channels_last(planes, 0, sdf_only ? 6 : NPL);
+    const int64_t ntiles = (N + 63) / 64;
+    const int64_t nwg = (ntiles + 3) / 4;
+    dim3 grid((unsigned)(nwg < 8192 ? nwg : 8192)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(CLv, SO, SV) \
+    hipLaunchKernelGGL((decode_fwd_kernel<CLv, SO, SV>), grid, block, 0, st, ps, *dec, bnd, pts, N, raw, feat)
+    if (sdf_only) {
+        if (cl) LAUNCH(true, true, false);
+        else LAUNCH(false, true, false);
+    } else if (feat) {
+        if (cl) LAUNCH(true, false, true);
+        else LAUNCH(false, false, true);
+    } else {
+        if (cl) LAUNCH(true, false, false);
+        else LAUNCH(false, false, false);
+    }
+#undef LAUNCH
+    return eslam_check_launch("decode_fwd_kernel");
+}

@@ -1,0 +1,434 @@
+// Ray generation and along-ray sampling kernels (K1-K4 of SURVEY.md section 2.1).
+// All of this is elementwise / per-ray work with a few bytes per ray; the kernels exist to remove ~40 tiny
+// PyTorch launches and 6 host syncs per iteration from the caller's critical path, and to produce z_vals that are
+// bit-identical to the reference's float32 arithmetic (explicitly rounded ops, no FMA contraction).
+#include "eslam_decode_tile.h"
+
+// hipcc contracts a*b+c into an FMA by default and its __fmul_rn/__fadd_rn are plain operators, so the explicit
+// rounding steps below only survive with contraction switched off for this translation unit's own code.
+#pragma clang fp contract(off)
+
+// ---------------------------------------------------------------------------------------------------------
+// K1: reference src/common.py:87-153
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pixel_dir(float u, float v, float fx, float fy, float cx, float cy, float d[3]) {
+    d[0] = __fdiv_rn(__fsub_rn(u, cx), fx);                 // common.py:92
+    d[1] = -__fdiv_rn(__fsub_rn(v, cy), fy);
+    d[2] = -1.0f;
+}
+
+__device__ __forceinline__ void rotate_dir(const float* __restrict__ c2w, const float d[3], float out[3]) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)                              // common.py:96: sum_k dirs[k] * R[j][k]
+        out[j] = __fadd_rn(__fadd_rn(__fmul_rn(d[0], c2w[4 * j + 0]), __fmul_rn(d[1], c2w[4 * j + 1])),
+                           __fmul_rn(d[2], c2w[4 * j + 2]));
+}
+
+__global__ void sample_rays_kernel(const int64_t* __restrict__ indices, int b, int n, int H0, int H1, int W0, int W1,
+                                   int H, int W, float fx, float fy, float cx, float cy,
+                                   const float* __restrict__ c2ws, const float* __restrict__ depths,
+                                   const float* __restrict__ colors, float* __restrict__ rays_o,
+                                   float* __restrict__ rays_d, float* __restrict__ depth, float* __restrict__ color) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b * n) return;
+    const int img = i / n;
+    const int ww = W1 - W0;
+    int64_t idx = indices[i];
+    const int64_t npix = (int64_t)ww * (H1 - H0);
+    idx = idx < 0 ? 0 : (idx >= npix ? npix - 1 : idx);       // never read outside the window
+    const int pu = (int)(idx % ww) + W0;
+    const int pv = (int)(idx / ww) + H0;
+    const int64_t pix = ((int64_t)img * H + pv) * W + pu;
+    depth[i] = depths[pix];                                   // common.py:120-121
+    color[3 * i + 0] = colors[3 * pix + 0];
+    color[3 * i + 1] = colors[3 * pix + 1];
+    color[3 * i + 2] = colors[3 * pix + 2];
+    float d[3], rd[3];
+    pixel_dir((float)pu, (float)pv, fx, fy, cx, cy, d);
+    const float* c2w = c2ws + 16 * img;
+    rotate_dir(c2w, d, rd);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        rays_d[3 * i + j] = rd[j];
+        rays_o[3 * i + j] = c2w[4 * j + 3];                   // common.py:97
+    }
+}
+
+// one workgroup per image: g_c2w[j][k<3] = sum_rays g_d[j] * dir[k],  g_c2w[j][3] = sum_rays g_o[j]
+__global__ __launch_bounds__(256) void sample_rays_bwd_kernel(const int64_t* __restrict__ indices, int n, int H0,
+                                                              int W0, int W1, float fx, float fy, float cx, float cy,
+                                                              const float* __restrict__ g_o,
+                                                              const float* __restrict__ g_d,
+                                                              float* __restrict__ g_c2ws) {
+    const int img = blockIdx.x;
+    const int ww = W1 - W0;
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.0f;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+        const int i = img * n + t;
+        const int64_t idx = indices[i];
+        float d[3];
+        pixel_dir((float)((int)(idx % ww) + W0), (float)((int)(idx / ww) + H0), fx, fy, cx, cy, d);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float gd = g_d ? g_d[3 * i + j] : 0.0f;
+            acc[4 * j + 0] += gd * d[0];
+            acc[4 * j + 1] += gd * d[1];
+            acc[4 * j + 2] += gd * d[2];
+            acc[4 * j + 3] += g_o ? g_o[3 * i + j] : 0.0f;
+        }
+    }
+    __shared__ float red[4][12];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const float s = wave_sum(acc[k]);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const int j = threadIdx.x >> 2, k = threadIdx.x & 3;
+        float v = 0.0f;
+        if (j < 3) v = (red[0][4 * j + k] + red[1][4 * j + k]) + (red[2][4 * j + k] + red[3][4 * j + k]);
+        g_c2ws[16 * img + threadIdx.x] = v;
+    }
+}
+
+// reference src/common.py:183-201
+__global__ void image_rays_kernel(int H, int W, float fx, float fy, float cx, float cy, const float* __restrict__ c2w,
+                                  float* __restrict__ rays_o, float* __restrict__ rays_d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H * W) return;
+    float d[3], rd[3];
+    pixel_dir((float)(i % W), (float)(i / W), fx, fy, cx, cy, d);
+    rotate_dir(c2w, d, rd);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        rays_d[3 * (int64_t)i + j] = rd[j];
+        rays_o[3 * (int64_t)i + j] = c2w[4 * j + 3];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// a2: reference src/Mapper.py:322-328, Tracker.py:175-181, Renderer.py:114-115
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float aabb_exit_dev(const float o[3], const float d[3], const Bound& bnd) {
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float t0 = __fdiv_rn(__fsub_rn(bnd.lo[k], o[k]), d[k]);
+        const float t1 = __fdiv_rn(__fsub_rn(bnd.hi[k], o[k]), d[k]);
+        // torch.max / torch.min propagate NaN (0/0 when a ray starts on a slab and runs along it)
+        float m = fmaxf(t0, t1);
+        if (t0 != t0 || t1 != t1) m = __builtin_nanf("");
+        if (k == 0) t = m;
+        else {
+            const bool nan = (t != t) || (m != m);
+            t = nan ? __builtin_nanf("") : fminf(t, m);
+        }
+    }
+    return t;
+}
+
+__global__ void aabb_exit_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d, int R,
+                                 const Bound bnd, float* __restrict__ t_exit) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    const float o[3] = {rays_o[3 * i], rays_o[3 * i + 1], rays_o[3 * i + 2]};
+    const float d[3] = {rays_d[3 * i], rays_d[3 * i + 1], rays_d[3 * i + 2]};
+    t_exit[i] = aabb_exit_dev(o, d, bnd);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K3: reference src/utils/Renderer.py:85-105 and :46-61
+// One wave per ray.  The two sequences are ascending, so the "sort" of Renderer.py:102 is a rank merge:
+// element position = own index + number of elements of the other sequence in front of it.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float jitter_one(const float* zs, int i, int S, float t) {
+    // Renderer.py:55-61
+    const float zi = zs[i];
+    const float lower = (i == 0) ? zi : __fmul_rn(0.5f, __fadd_rn(zi, zs[i - 1]));
+    const float upper = (i == S - 1) ? zi : __fmul_rn(0.5f, __fadd_rn(zs[i + 1], zi));
+    return __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), t));
+}
+
+__global__ __launch_bounds__(256) void sample_z_kernel(const float* __restrict__ gt_depth, int R, int n_strat,
+                                                       int n_imp, float c15, float c3,
+                                                       const float* __restrict__ t_free,
+                                                       const float* __restrict__ t_surf,
+                                                       const float* __restrict__ t_rand, float* __restrict__ z_vals) {
+    __shared__ float zs_all[4][ESLAM_MAX_SAMPLES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ray = blockIdx.x * 4 + wave;
+    if (ray >= R) return;
+    const float d = gt_depth[ray];
+    if (!(d > 0.0f)) return;                       // Renderer.py:92: handled by the importance sampler
+    const int S = n_strat + n_imp;
+    float* zs = zs_all[wave];
+    const float d12 = __fmul_rn(1.2f, d);          // Renderer.py:100
+    const float dlo = __fsub_rn(d, c15);           // Renderer.py:97
+    for (int i = lane; i < S; i += WAVE) {
+        float val;
+        int pos;
+        if (i < n_strat) {
+            val = __fadd_rn(0.0f, __fmul_rn(d12, t_free[i]));
+            int cnt = 0;
+            for (int j = 0; j < n_imp; ++j) cnt += (__fadd_rn(dlo, __fmul_rn(c3, t_surf[j])) < val) ? 1 : 0;
+            pos = i + cnt;
+        } else {
+            const int j = i - n_strat;
+            val = __fadd_rn(dlo, __fmul_rn(c3, t_surf[j]));
+            int cnt = 0;
+            for (int k = 0; k < n_strat; ++k) cnt += (__fadd_rn(0.0f, __fmul_rn(d12, t_free[k])) <= val) ? 1 : 0;
+            pos = j + cnt;
+        }
+        zs[pos] = val;
+    }
+    WAVE_SYNC();
+    float* out = z_vals + (int64_t)ray * S;
+    for (int i = lane; i < S; i += WAVE)
+        out[i] = t_rand ? jitter_one(zs, i, S, t_rand[(int64_t)ray * S + i]) : zs[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K4: reference src/utils/Renderer.py:108-134 + src/common.py:41-77.  One wave per zero-depth ray.
+// ---------------------------------------------------------------------------------------------------------
+template <bool CL>
+__global__ __launch_bounds__(256, 4) void importance_z_kernel(const PlaneSet planes, const eslam_decoders_t dec,
+                                                           const Bound bnd, const float* __restrict__ rays_o,
+                                                           const float* __restrict__ rays_d,
+                                                           const float* __restrict__ gt_depth, int R, int n_strat,
+                                                           int n_imp, const float* __restrict__ t_free,
+                                                           const float* __restrict__ t_rand_uni,
+                                                           const float* __restrict__ u_rand,
+                                                           float* __restrict__ z_vals) {
+    __shared__ __attribute__((aligned(16))) float wlds[2 * DEC_LDS];
+    __shared__ float zu_all[4][ESLAM_MAX_SAMPLES];      // jittered uniform samples, then the merged list
+    __shared__ float wt_all[4][ESLAM_MAX_SAMPLES];      // weights -> cdf
+    __shared__ float zn_all[4][ESLAM_MAX_SAMPLES];      // importance samples
+    stage_decoder_weights(wlds, dec, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int ray = blockIdx.x * 4 + wave;
+    if (ray >= R) return;
+    if (gt_depth[ray] > 0.0f) return;
+    float* zu = zu_all[wave];
+    float* wt = wt_all[wave];
+    float* zn = zn_all[wave];
+    const float o[3] = {rays_o[3 * ray], rays_o[3 * ray + 1], rays_o[3 * ray + 2]};
+    const float d[3] = {rays_d[3 * ray], rays_d[3 * ray + 1], rays_d[3 * ray + 2]};
+    const float far = __fadd_rn(aabb_exit_dev(o, d, bnd), 0.01f);          // Renderer.py:114-117
+    const float beta = dec.beta[0];
+
+    // Renderer.py:119: near*(1-t) + far*t with near = 0
+    for (int i = lane; i < n_strat; i += WAVE) {
+        const float t = t_free[i];
+        wt[i] = __fadd_rn(__fmul_rn(0.0f, __fsub_rn(1.0f, t)), __fmul_rn(far, t));
+    }
+    WAVE_SYNC();
+    for (int i = lane; i < n_strat; i += WAVE)
+        zu[i] = t_rand_uni ? jitter_one(wt, i, n_strat, t_rand_uni[(int64_t)ray * n_strat + i]) : wt[i];
+    WAVE_SYNC();
+
+    // SDF decode of the n_strat points (geometry planes only), alpha, transmittance, weights (Renderer.py:122-129)
+    float trans_in = 1.0f;
+    for (int c0 = 0; c0 < n_strat; c0 += WAVE) {
+        const int nvalid = min(WAVE, n_strat - c0);
+        const int nblk = (nvalid + 15) >> 4;
+        float4_t out = *(const float4_t*)(wlds + DEC_B3);
+#pragma unroll 1
+        for (int b = 0; b < nblk; ++b) {
+            {
+                const int oz0 = opaque_zero(b);
+                const float z = zu[min(c0 + 16 * b + r, n_strat - 1)];
+                // Renderer.py:122: o + d*z (mul then add, as torch does)
+                const float x = norm_coord(__fadd_rn(o[0], __fmul_rn(d[0], z)), bnd.lo[0], bnd.hi[0]);
+                const float y = norm_coord(__fadd_rn(o[1], __fmul_rn(d[1], z)), bnd.lo[1], bnd.hi[1]);
+                const float zz = norm_coord(__fadd_rn(o[2], __fmul_rn(d[2], z)), bnd.lo[2], bnd.hi[2]);
+                float feat[16];
+                gather_features<CL>(planes, 0, x, y, zz, q, feat, oz0);
+                DecFrag f;
+                load_dec_frag(f, wlds + oz0, r, q);
+                float4_t h1, h2;
+                mlp_hidden(f, feat, h1, h2);
+                mlp_out_accum(f, h2, b, r, out);
+            }
+        }
+        const bool valid = lane < nvalid;
+        const float sdf = tanhf(out[0]);
+        float alpha = 1.0f - expf(-beta * sigmoidf_(-sdf * beta));
+        if (!valid) alpha = 0.0f;
+        const float fac = valid ? (1.0f - alpha) + 1e-10f : 1.0f;
+        const float pin = wave_incl_prod(fac, lane);
+        float pex = __shfl_up(pin, 1, WAVE);
+        if (lane == 0) pex = 1.0f;
+        if (valid) wt[c0 + lane] = alpha * (trans_in * pex);
+        trans_in *= __shfl(pin, 63, WAVE);
+    }
+    WAVE_SYNC();
+
+    // sample_pdf (common.py:41-77): bins = mids (n_strat-1), pdf = weights[1:-1] un-normalised (n_strat-2)
+    const int nb = n_strat - 1;             // len(bins) == len(cdf)
+    if (lane == 0) {                        // sequential cumsum, the order torch.cumsum uses on one row
+        float run = 0.0f;
+        float prev = wt[1];
+        wt[0] = 0.0f;                       // cdf[0] = 0  (overwrites weights[0], unused by sample_pdf)
+        for (int k = 1; k < nb; ++k) {
+            const float wk = prev;          // weights[k] (pdf[k-1]); read before it is overwritten
+            prev = wt[k + 1];
+            run = __fadd_rn(run, wk);
+            wt[k] = run;                    // cdf[k]
+        }
+    }
+    WAVE_SYNC();
+    for (int i = lane; i < n_imp; i += WAVE) {
+        const float u = u_rand[(int64_t)ray * n_imp + i];
+        int inds = 0;                       // searchsorted(cdf, u, right=True): #entries <= u
+        for (int k = 0; k < nb; ++k) inds += (wt[k] <= u) ? 1 : 0;
+        const int below = max(inds - 1, 0);
+        const int above = min(nb - 1, inds);
+        const float c0v = wt[below], c1v = wt[above];
+        const float b0 = __fmul_rn(0.5f, __fadd_rn(zu[below + 1], zu[below]));
+        const float b1 = __fmul_rn(0.5f, __fadd_rn(zu[above + 1], zu[above]));
+        float denom = __fsub_rn(c1v, c0v);
+        if (denom < 1e-5f) denom = 1.0f;
+        const float t = __fdiv_rn(__fsub_rn(u, c0v), denom);
+        zn[i] = __fadd_rn(b0, __fmul_rn(t, __fsub_rn(b1, b0)));
+    }
+    WAVE_SYNC();
+
+    // Renderer.py:133: sort(cat(z_uni, z_samples)) as a stable rank sort (values are what matter)
+    const int S = n_strat + n_imp;
+    float* out_row = z_vals + (int64_t)ray * S;
+    for (int i = lane; i < S; i += WAVE) {
+        const float v = (i < n_strat) ? zu[i] : zn[i - n_strat];
+        int pos = 0;
+        for (int k = 0; k < S; ++k) {
+            const float o2 = (k < n_strat) ? zu[k] : zn[k - n_strat];
+            pos += (o2 < v || (o2 == v && k < i)) ? 1 : 0;
+        }
+        out_row[pos] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+bool eslam_planes_channels_last(const eslam_plane_t* planes, int first, int count);
+int eslam_validate_planes(const eslam_plane_t* planes, int first, int count);
+
+static Bound make_bound(const float* b6) {
+    Bound b;
+    for (int k = 0; k < 3; ++k) {
+        b.lo[k] = b6[2 * k];
+        b.hi[k] = b6[2 * k + 1];
+        b.inv_len_unused[k] = 0.f;
+    }
+    return b;
+}
+
+extern "C" int eslam_sample_rays(const int64_t* indices, int b, int n, int H0, int H1, int W0, int W1, int H, int W,
+                                 float fx, float fy, float cx, float cy, const float* c2ws, const float* depths,
+                                 const float* colors, float* rays_o, float* rays_d, float* depth, float* color,
+                                 eslam_stream_t stream) {
+    if (b <= 0 || n <= 0) return 0;
+    if (!(0 <= H0 && H0 < H1 && H1 <= H && 0 <= W0 && W0 < W1 && W1 <= W)) {
+        eslam_set_error("eslam_sample_rays: bad window [%d,%d)x[%d,%d) for image %dx%d", H0, H1, W0, W1, H, W);
+        return 1;
+    }
+    if (!indices || !c2ws || !depths || !colors || !rays_o || !rays_d || !depth || !color) {
+        eslam_set_error("eslam_sample_rays: null argument");
+        return 1;
+    }
+    const int total = b * n;
+    hipLaunchKernelGGL(sample_rays_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, indices, b, n,
+                       H0, H1, W0, W1, H, W, fx, fy, cx, cy, c2ws, depths, colors, rays_o, rays_d, depth, color);
+    return eslam_check_launch("sample_rays_kernel");
+}
+
+extern "C" int eslam_sample_rays_bwd(const int64_t* indices, int b, int n, int H0, int W0, int W1, float fx, float fy,
+                                     float cx, float cy, const float* g_rays_o, const float* g_rays_d, float* g_c2ws,
+                                     eslam_stream_t stream) {
+    if (b <= 0) return 0;
+    if (!indices || !g_c2ws || W1 <= W0) {
+        eslam_set_error("eslam_sample_rays_bwd: bad argument");
+        return 1;
+    }
+    hipLaunchKernelGGL(sample_rays_bwd_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, indices, n, H0, W0, W1, fx,
+                       fy, cx, cy, g_rays_o, g_rays_d, g_c2ws);
+    return eslam_check_launch("sample_rays_bwd_kernel");
+}
+
+extern "C" int eslam_image_rays(int H, int W, float fx, float fy, float cx, float cy, const float* c2w, float* rays_o,
+                                float* rays_d, eslam_stream_t stream) {
+    if (H <= 0 || W <= 0) return 0;
+    if (!c2w || !rays_o || !rays_d) {
+        eslam_set_error("eslam_image_rays: null argument");
+        return 1;
+    }
+    hipLaunchKernelGGL(image_rays_kernel, dim3((H * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, H, W, fx, fy,
+                       cx, cy, c2w, rays_o, rays_d);
+    return eslam_check_launch("image_rays_kernel");
+}
+
+extern "C" int eslam_aabb_exit(const float* rays_o, const float* rays_d, int R, const float* bound6_host,
+                               float* t_exit, eslam_stream_t stream) {
+    if (R <= 0) return 0;
+    if (!rays_o || !rays_d || !bound6_host || !t_exit) {
+        eslam_set_error("eslam_aabb_exit: null argument");
+        return 1;
+    }
+    hipLaunchKernelGGL(aabb_exit_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, R,
+                       make_bound(bound6_host), t_exit);
+    return eslam_check_launch("aabb_exit_kernel");
+}
+
+extern "C" int eslam_sample_z(const float* gt_depth, int R, int n_strat, int n_imp, double truncation,
+                              const float* t_free, const float* t_surf, const float* t_rand, float* z_vals,
+                              eslam_stream_t stream) {
+    if (R <= 0) return 0;
+    if (n_strat < 1 || n_imp < 0 || n_strat + n_imp > ESLAM_MAX_SAMPLES) {
+        eslam_set_error("eslam_sample_z: n_strat=%d n_imp=%d unsupported (sum <= %d)", n_strat, n_imp,
+                        ESLAM_MAX_SAMPLES);
+        return 1;
+    }
+    if (!gt_depth || !t_free || (n_imp > 0 && !t_surf) || !z_vals) {
+        eslam_set_error("eslam_sample_z: null argument");
+        return 1;
+    }
+    // Renderer.py:97: (1.5 * truncation) and (3 * truncation) are Python-float products, cast to float32 by torch
+    const float c15 = (float)(1.5 * truncation);
+    const float c3 = (float)(3.0 * truncation);
+    hipLaunchKernelGGL(sample_z_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, gt_depth, R, n_strat,
+                       n_imp, c15, c3, t_free, t_surf, t_rand, z_vals);
+    return eslam_check_launch("sample_z_kernel");
+}
+
+extern "C" int eslam_importance_z(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
+                                  const float* rays_o, const float* rays_d, const float* gt_depth, int R, int n_strat,
+                                  int n_imp, const float* t_free, const float* t_rand_uni, const float* u,
+                                  float* z_vals, eslam_stream_t stream) {
+    if (R <= 0) return 0;
+    if (n_strat < 3 || n_imp < 1 || n_strat + n_imp > ESLAM_MAX_SAMPLES) {
+        eslam_set_error("eslam_importance_z: n_strat=%d n_imp=%d unsupported", n_strat, n_imp);
+        return 1;
+    }
+    if (!planes || !dec || !bound6_host || !rays_o || !rays_d || !gt_depth || !t_free || !u || !z_vals) {
+        eslam_set_error("eslam_importance_z: null argument");
+        return 1;
+    }
+    if (eslam_validate_planes(planes, 0, 6)) return 1;
+    PlaneSet ps;
+    for (int i = 0; i < NPL; ++i) ps.p[i] = planes[i < 6 ? i : i - 6];
+    const Bound bnd = make_bound(bound6_host);
+    dim3 grid((R + 3) / 4), block(256);
+    if (eslam_planes_channels_last(planes, 0, 6))
+        hipLaunchKernelGGL((importance_z_kernel<true>), grid, block, 0, (hipStream_t)stream, ps, *dec, bnd, rays_o,
+                           rays_d, gt_depth, R, n_strat, n_imp, t_free, t_rand_uni, u, z_vals);
+    else
+        hipLaunchKernelGGL((importance_z_kernel<false>), grid, block, 0, (hipStream_t)stream, ps, *dec, bnd, rays_o,
+                           rays_d, gt_depth, R, n_strat, n_imp, t_free, t_rand_uni, u, z_vals);
+    return eslam_check_launch("importance_z_kernel");
+}

@@ -1,0 +1,107 @@
+"""Synthetic mapping workload shared by bench.py, __graft_entry__.smoke() and the tests.
+
+Scene = bound / intrinsics / plane shapes of a reference scene; planes ~ N(0, 0.01^2) (reference
+src/ESLAM.py:201-210), decoders with default nn.Linear init, beta = 10, camera at the AABB centre with identity
+rotation, depth image ~ U(0.5, 2.5) m, colour ~ U(0,1).  Rays come from get_samples on the whole image followed
+by the caller-side AABB pre-filter of reference src/Mapper.py:322-332, exactly as a mapping iteration does.
+"""
+from types import SimpleNamespace
+
+import torch
+
+from . import losses, ops, scene as scn, synth
+from .src.common import get_samples_at
+from .src.networks.decoders import Decoders
+from .src.utils.Renderer import Renderer
+
+
+class Workload:
+    def __init__(self, scene_name, R, n_strat, n_imp, device, zero_frac=0.0, seed=0, channels_last=True,
+                 rays_grad=False, planes="normal"):
+        dev = torch.device(device)
+        self.device = dev
+        sc = scn.make_scene(scene_name)
+        self.scene = sc
+        self.truncation = sc.truncation
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed)
+        if planes == "normal":
+            pl = scn.random_planes(sc, dev, generator=gen, channels_last=channels_last)
+        else:
+            pl = scn.synth_planes(sc, device=dev, channels_last=channels_last)
+        self.planes = tuple([torch.nn.Parameter(p) for p in grp] for grp in pl)      # as Mapper.py:254-266
+        torch.manual_seed(seed)
+        self.decoders = Decoders(learnable_beta=sc.learnable_beta).to(dev)
+        self.decoders.bound = sc.bound
+        cfg = sc.cfg(perturb=True)
+        cfg["rendering"]["n_stratified"] = n_strat
+        cfg["rendering"]["n_importance"] = n_imp
+        self.n_strat, self.n_imp, self.S = n_strat, n_imp, n_strat + n_imp
+        eslam = SimpleNamespace(bound=sc.bound, device=dev, H=sc.H, W=sc.W, fx=sc.fx, fy=sc.fy, cx=sc.cx, cy=sc.cy)
+        self.renderer = Renderer(cfg, eslam)
+        self.c2w = scn.center_pose(sc)
+        depth_img = torch.from_numpy(synth.depth_image(sc.H, sc.W, 10 + seed, zero_frac)).to(dev)[None]
+        color_img = torch.from_numpy(synth.color_image(sc.H, sc.W, 12 + seed)).to(dev)[None]
+        idx = torch.from_numpy(synth.hash_randint(sc.H * sc.W, (R,), 50_000 + seed)).to(dev)
+        c2ws = self.c2w[None].to(dev)
+        with torch.no_grad():
+            ro, rd, gd, gc = get_samples_at(idx, 0, sc.H, 0, sc.W, R, sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, c2ws,
+                                            depth_img, color_img)
+            inside = ops.aabb_exit(ro, rd, ops.bound_to_host(sc.bound)) >= gd           # Mapper.py:322-332
+        self.rays_o = ro[inside].contiguous().requires_grad_(rays_grad)
+        self.rays_d = rd[inside].contiguous().requires_grad_(rays_grad)
+        self.gt_depth = gd[inside].contiguous()
+        self.gt_color = gc[inside].contiguous()
+        self.R = int(self.rays_o.shape[0])
+        # fixed random numbers / cotangents for the reproducible (test) paths
+        self._rand = (torch.from_numpy(synth.hash_uniform((self.R, self.S), 90_000)).to(dev),
+                      torch.from_numpy(synth.hash_uniform((self.R, n_strat), 90_001)).to(dev),
+                      torch.from_numpy(synth.hash_uniform((self.R, n_imp), 90_002)).to(dev))
+        self._cot = (torch.from_numpy(synth.hash_uniform((self.R,), 91_000)).to(dev) - 0.5,
+                     torch.from_numpy(synth.hash_uniform((self.R, 3), 91_001)).to(dev) - 0.5,
+                     (torch.from_numpy(synth.hash_uniform((self.R, self.S), 91_002)).to(dev) - 0.5) * 0.1)
+
+    @property
+    def plane_list(self):
+        return [p for grp in self.planes for p in grp]
+
+    def params(self):
+        return self.plane_list + list(self.decoders.parameters())
+
+    def _slice(self, shard):
+        if shard is None:
+            return slice(0, self.R)
+        k, n = shard
+        per = (self.R + n - 1) // n
+        return slice(k * per, min(self.R, (k + 1) * per))
+
+    def forward(self, shard=None, fixed_rand=True):
+        sl = self._slice(shard)
+        rand = tuple(t[sl] for t in self._rand) if fixed_rand else None
+        return self.renderer.render_batch_ray(self.planes, self.decoders, self.rays_d[sl], self.rays_o[sl],
+                                              self.device, self.truncation, gt_depth=self.gt_depth[sl], _rand=rand)
+
+    def backward_with(self, out, scale=1.0, shard=None):
+        """Back-propagate fixed pseudo-random cotangents (a loss that is linear in the outputs); returns every
+        parameter gradient as a list of tensors."""
+        sl = self._slice(shard)
+        depth, color, sdf, _ = out
+        a, b, c = (t[sl] for t in self._cot)
+        for p in self.params():
+            p.grad = None
+        (scale * ((depth * a).sum() + (color * b).sum() + (sdf * c).sum())).backward()
+        return [p.grad.detach().clone() for p in self.params()]
+
+    def step(self):
+        """One mapping iteration minus the optimiser step: render, loss, backward."""
+        for p in self.params():
+            p.grad = None
+        depth, color, sdf, z = self.renderer.render_batch_ray(self.planes, self.decoders, self.rays_d, self.rays_o,
+                                                              self.device, self.truncation, gt_depth=self.gt_depth)
+        loss = losses.mapping_loss(depth, color, sdf, z, self.gt_depth, self.gt_color, self.truncation)
+        loss.backward()
+        return loss
+
+
+def make_workload(scene_name, R, n_strat, n_imp, device, **kw):
+    return Workload(scene_name, R, n_strat, n_imp, device, **kw)

@@ -1,0 +1,359 @@
+"""torch.autograd glue around the C-ABI kernels.  PyTorch is plumbing here (device memory, streams, the
+autograd graph the reference's Mapper/Tracker call .backward() on); all arithmetic is in the HIP library.
+
+Nothing in this file computes on the CPU: tensors that are not on a GPU raise.
+"""
+import ctypes
+
+import torch
+
+from . import _hip
+
+_const_cache = {}
+
+
+def _cached(key, make):
+    t = _const_cache.get(key)
+    if t is None:
+        t = make()
+        _const_cache[key] = t
+    return t
+
+
+def beta_tensor(beta, device):
+    """decoders.beta is an nn.Parameter or the Python int 10 (reference decoders.py:59-62)."""
+    if torch.is_tensor(beta):
+        return beta
+    dev = torch.device(device)
+    return _cached(("beta", float(beta), dev.index), lambda: torch.full((1,), float(beta), device=dev))
+
+
+def linspace01(n, device):
+    dev = torch.device(device)
+    return _cached(("lin", n, dev.index), lambda: torch.linspace(0.0, 1.0, steps=n, device=dev))
+
+
+def decoder_params(decoders):
+    """The 12 tensors in C-ABI order from our Decoders or the reference's (same attribute names)."""
+    return [decoders.linears[0].weight, decoders.linears[0].bias, decoders.linears[1].weight,
+            decoders.linears[1].bias, decoders.output_linear.weight, decoders.output_linear.bias,
+            decoders.c_linears[0].weight, decoders.c_linears[0].bias, decoders.c_linears[1].weight,
+            decoders.c_linears[1].bias, decoders.c_output_linear.weight, decoders.c_output_linear.bias]
+
+
+def bound_to_host(bound):
+    """[3,2] tensor (the reference keeps decoders.bound on the CPU, ESLAM.py:173) -> 6 floats."""
+    if torch.is_tensor(bound):
+        return tuple(float(v) for v in bound.detach().reshape(-1).tolist())
+    return tuple(float(v) for v in bound)
+
+
+def _c(t):
+    return t if t is None or t.is_contiguous() else t.contiguous()
+
+
+def _split_planes(flat12):
+    return tuple([flat12[2 * g], flat12[2 * g + 1]] for g in range(6))
+
+
+def _alloc_plane_grads(planes):
+    """One flat zero buffer, 12 views with the planes' own strides (so autograd can adopt them without a copy
+    and a multi-GPU caller can all-reduce the flat buffer)."""
+    sizes = [p.numel() for p in planes]
+    flat = torch.zeros(sum(sizes), device=planes[0].device, dtype=torch.float32)
+    views, off = [], 0
+    for p, n in zip(planes, sizes):
+        dense = p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last)
+        if not dense:
+            raise RuntimeError("planes must be dense (contiguous or channels_last)")
+        views.append(flat[off:off + n].as_strided(p.shape, p.stride()))
+        off += n
+    return flat, views
+
+
+def _split_dec_grads(g_dec):
+    out, off = [], 0
+    for _, _, shape in _hip.DEC_FIELDS:
+        n = 1
+        for s in shape:
+            n *= s
+        out.append(g_dec[off:off + n].view(shape))
+        off += n
+    return out
+
+
+class RenderFn(torch.autograd.Function):
+    """depth, rgb, sdf = RenderFn.apply(rays_o, rays_d, z_vals, bound6, beta, *12 planes, *12 decoder params)
+
+    Forward = eslam_render_fwd, backward = eslam_render_bwd (reference: Renderer.py:136-147 and its autograd)."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, z_vals, bound6, beta, *tensors):
+        planes, params = tensors[:12], tensors[12:24]
+        for n, t in (("rays_o", rays_o), ("rays_d", rays_d), ("z_vals", z_vals)):
+            _hip.require_gpu_f32(n, t)
+        rays_o, rays_d, z_vals = _c(rays_o.detach()), _c(rays_d.detach()), _c(z_vals.detach())
+        R, S = z_vals.shape
+        dev = rays_o.device
+        lib = _hip.lib()
+        arr, _ = _hip.make_planes(_split_planes([p.detach() for p in planes]))
+        dec, keep = _hip.make_decoders([p.detach() for p in params], beta.detach())
+        needs = any(ctx.needs_input_grad)
+        depth = torch.empty(R, device=dev)
+        rgb = torch.empty(R, 3, device=dev)
+        sdf = torch.empty(R, S, device=dev)
+        raw_rgb = torch.empty(R, S, 3, device=dev) if needs else None
+        feat = torch.empty(R * S, 128, device=dev) if needs else None
+        with torch.cuda.device(dev):
+            _hip.check(lib.eslam_render_fwd(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(rays_o),
+                                            _hip.ptr(rays_d), _hip.ptr(z_vals), R, S, _hip.ptr(depth), _hip.ptr(rgb),
+                                            _hip.ptr(sdf), _hip.ptr(raw_rgb), _hip.ptr(feat),
+                                            _hip.stream_handle(dev)), "eslam_render_fwd")
+        if needs:
+            ctx.bound6 = bound6
+            ctx.save_for_backward(rays_o, rays_d, z_vals, sdf, raw_rgb, feat, beta, *planes, *params)
+        return depth, rgb, sdf
+
+    @staticmethod
+    def backward(ctx, g_depth, g_rgb, g_sdf):
+        saved = ctx.saved_tensors
+        rays_o, rays_d, z_vals, sdf, raw_rgb, feat, beta = saved[:7]
+        planes, params = saved[7:19], saved[19:31]
+        R, S = z_vals.shape
+        dev = rays_o.device
+        lib = _hip.lib()
+        need = ctx.needs_input_grad
+        need_planes = any(need[5:17])
+        need_rays = need[0] or need[1]
+        grads = None
+        if need_planes:
+            _, grads = _alloc_plane_grads(planes)
+        arr, _ = _hip.make_planes(_split_planes([p.detach() for p in planes]), grads)
+        dec, keep = _hip.make_decoders([p.detach() for p in params], beta.detach())
+        g_dec = torch.empty(_hip.N_DEC_PARAMS, device=dev)
+        g_beta = torch.empty(1, device=dev)
+        g_ro = torch.empty(R, 3, device=dev) if need_rays else None
+        g_rd = torch.empty(R, 3, device=dev) if need_rays else None
+        ws = torch.empty(lib.eslam_bwd_workspace_bytes(R * S), dtype=torch.uint8, device=dev)
+        g_depth, g_rgb, g_sdf = _c(g_depth), _c(g_rgb), _c(g_sdf)
+        with torch.cuda.device(dev):
+            _hip.check(lib.eslam_render_bwd(arr, ctypes.byref(dec), _hip.make_bound(ctx.bound6), _hip.ptr(rays_o),
+                                            _hip.ptr(rays_d), _hip.ptr(z_vals), R, S, _hip.ptr(sdf), _hip.ptr(raw_rgb),
+                                            _hip.ptr(feat), _hip.ptr(g_depth), _hip.ptr(g_rgb), _hip.ptr(g_sdf),
+                                            _hip.ptr(g_dec), _hip.ptr(g_beta), _hip.ptr(g_ro), _hip.ptr(g_rd),
+                                            _hip.ptr(ws), _hip.stream_handle(dev)), "eslam_render_bwd")
+        dec_grads = _split_dec_grads(g_dec)
+        out = [g_ro if need[0] else None, g_rd if need[1] else None, None, None, g_beta if need[4] else None]
+        out += [grads[i] if (need_planes and need[5 + i]) else None for i in range(12)]
+        out += [dec_grads[i] if need[17 + i] else None for i in range(12)]
+        return tuple(out)
+
+
+class DecodeFn(torch.autograd.Function):
+    """raw[N,4] = DecodeFn.apply(pts[N,3], bound6, *12 planes, *12 decoder params)   (decoders.py:127-146)"""
+
+    @staticmethod
+    def forward(ctx, pts, bound6, dummy_beta, *tensors):
+        planes, params = tensors[:12], tensors[12:24]
+        _hip.require_gpu_f32("p", pts)
+        pts = _c(pts.detach())
+        N = pts.shape[0]
+        dev = pts.device
+        lib = _hip.lib()
+        arr, _ = _hip.make_planes(_split_planes([p.detach() for p in planes]))
+        dec, keep = _hip.make_decoders([p.detach() for p in params], dummy_beta)
+        needs = any(ctx.needs_input_grad)
+        raw = torch.empty(N, 4, device=dev)
+        feat = torch.empty(N, 128, device=dev) if needs else None
+        with torch.cuda.device(dev):
+            _hip.check(lib.eslam_decode_fwd(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(pts), N, 0,
+                                            _hip.ptr(raw), _hip.ptr(feat), _hip.stream_handle(dev)), "eslam_decode_fwd")
+        if needs:
+            ctx.bound6 = bound6
+            ctx.save_for_backward(pts, raw, feat, dummy_beta, *planes, *params)
+        return raw
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        saved = ctx.saved_tensors
+        pts, raw, feat, dummy_beta = saved[:4]
+        planes, params = saved[4:16], saved[16:28]
+        N = pts.shape[0]
+        dev = pts.device
+        lib = _hip.lib()
+        need = ctx.needs_input_grad
+        need_planes = any(need[3:15])
+        grads = None
+        if need_planes:
+            _, grads = _alloc_plane_grads(planes)
+        arr, _ = _hip.make_planes(_split_planes([p.detach() for p in planes]), grads)
+        dec, keep = _hip.make_decoders([p.detach() for p in params], dummy_beta)
+        g_dec = torch.empty(_hip.N_DEC_PARAMS, device=dev)
+        g_pts = torch.empty(N, 3, device=dev) if need[0] else None
+        ws = torch.empty(lib.eslam_bwd_workspace_bytes(N), dtype=torch.uint8, device=dev)
+        g_raw = _c(g_raw)
+        with torch.cuda.device(dev):
+            _hip.check(lib.eslam_decode_bwd(arr, ctypes.byref(dec), _hip.make_bound(ctx.bound6), _hip.ptr(pts), N,
+                                            _hip.ptr(raw), _hip.ptr(feat), _hip.ptr(g_raw), _hip.ptr(g_dec),
+                                            _hip.ptr(g_pts), _hip.ptr(ws), _hip.stream_handle(dev)), "eslam_decode_bwd")
+        dec_grads = _split_dec_grads(g_dec)
+        out = [g_pts, None, None]
+        out += [grads[i] if (need_planes and need[3 + i]) else None for i in range(12)]
+        out += [dec_grads[i] if need[15 + i] else None for i in range(12)]
+        return tuple(out)
+
+
+def decode_sdf_only(pts, bound6, all_planes, decoders):
+    """Geometry planes + SDF decoder only, no autograd (reference decoders.py:87-105 under no_grad)."""
+    _hip.require_gpu_f32("p", pts)
+    pts = _c(pts.detach())
+    N = pts.shape[0]
+    dev = pts.device
+    lib = _hip.lib()
+    geo = tuple(all_planes[:3]) + tuple(all_planes[:3])
+    arr, _ = _hip.make_planes(tuple([p.detach() for p in grp] for grp in geo))
+    dec, keep = _hip.make_decoders([p.detach() for p in decoder_params(decoders)], beta_tensor(10, dev))
+    out = torch.empty(N, device=dev)
+    with torch.cuda.device(dev):
+        _hip.check(lib.eslam_decode_fwd(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(pts), N, 1,
+                                        _hip.ptr(out), None, _hip.stream_handle(dev)), "eslam_decode_fwd(sdf)")
+    return out
+
+
+class SampleRaysFn(torch.autograd.Function):
+    """rays_o, rays_d, depth, color = SampleRaysFn.apply(c2ws, indices, depths, colors, geom)   (common.py:87-153)"""
+
+    @staticmethod
+    def forward(ctx, c2ws, indices, depths, colors, geom):
+        H0, H1, W0, W1, n, H, W, fx, fy, cx, cy = geom
+        _hip.require_gpu_f32("c2ws", c2ws)
+        _hip.require_gpu_f32("depths", depths)
+        _hip.require_gpu_f32("colors", colors)
+        c2 = _c(c2ws.detach())
+        b = c2.shape[0]
+        dev = c2.device
+        depths, colors, indices = _c(depths), _c(colors), _c(indices)
+        if depths.shape != (b, H, W) or colors.shape != (b, H, W, 3):
+            raise RuntimeError(f"get_samples: depths {tuple(depths.shape)} / colors {tuple(colors.shape)} do not match "
+                               f"b={b}, H={H}, W={W}")
+        if indices.dtype != torch.int64 or indices.numel() != b * n:
+            raise RuntimeError("get_samples: indices must be int64 [b*n]")
+        ro = torch.empty(b * n, 3, device=dev)
+        rd = torch.empty(b * n, 3, device=dev)
+        d = torch.empty(b * n, device=dev)
+        c = torch.empty(b * n, 3, device=dev)
+        with torch.cuda.device(dev):
+            _hip.check(_hip.lib().eslam_sample_rays(_hip.ptr(indices), b, n, H0, H1, W0, W1, H, W, fx, fy, cx, cy,
+                                                    _hip.ptr(c2), _hip.ptr(depths), _hip.ptr(colors), _hip.ptr(ro),
+                                                    _hip.ptr(rd), _hip.ptr(d), _hip.ptr(c), _hip.stream_handle(dev)),
+                       "eslam_sample_rays")
+        ctx.geom = geom
+        ctx.b = b
+        ctx.save_for_backward(indices)
+        ctx.mark_non_differentiable(d, c)
+        return ro, rd, d, c
+
+    @staticmethod
+    def backward(ctx, g_ro, g_rd, _gd, _gc):
+        (indices,) = ctx.saved_tensors
+        H0, H1, W0, W1, n, H, W, fx, fy, cx, cy = ctx.geom
+        dev = indices.device
+        g = torch.empty(ctx.b, 4, 4, device=dev)
+        g_ro, g_rd = _c(g_ro), _c(g_rd)
+        with torch.cuda.device(dev):
+            _hip.check(_hip.lib().eslam_sample_rays_bwd(_hip.ptr(indices), ctx.b, n, H0, W0, W1, fx, fy, cx, cy,
+                                                        _hip.ptr(g_ro), _hip.ptr(g_rd), _hip.ptr(g),
+                                                        _hip.stream_handle(dev)), "eslam_sample_rays_bwd")
+        return g, None, None, None, None
+
+
+def image_rays(H, W, fx, fy, cx, cy, c2w):
+    _hip.require_gpu_f32("c2w", c2w)
+    c2 = _c(c2w.detach())
+    dev = c2.device
+    ro = torch.empty(H * W, 3, device=dev)
+    rd = torch.empty(H * W, 3, device=dev)
+    with torch.cuda.device(dev):
+        _hip.check(_hip.lib().eslam_image_rays(H, W, fx, fy, cx, cy, _hip.ptr(c2), _hip.ptr(ro), _hip.ptr(rd),
+                                               _hip.stream_handle(dev)), "eslam_image_rays")
+    return ro, rd
+
+
+def aabb_exit(rays_o, rays_d, bound6):
+    _hip.require_gpu_f32("rays_o", rays_o)
+    ro, rd = _c(rays_o.detach()), _c(rays_d.detach())
+    R = ro.shape[0]
+    t = torch.empty(R, device=ro.device)
+    with torch.cuda.device(ro.device):
+        _hip.check(_hip.lib().eslam_aabb_exit(_hip.ptr(ro), _hip.ptr(rd), R, _hip.make_bound(bound6), _hip.ptr(t),
+                                              _hip.stream_handle(ro.device)), "eslam_aabb_exit")
+    return t
+
+
+def sample_z(rays_o, rays_d, gt_depth, all_planes, decoders, bound6, truncation, n_strat, n_imp, perturb,
+             rand=None):
+    """z_vals [R,S] of reference Renderer.py:85-134, sync-free: both samplers run over all rays and each skips
+    the rays that belong to the other.  rand = (t_rand [R,S], t_rand_uni [R,n_strat], u [R,n_imp]) or None to
+    draw them with torch.rand."""
+    _hip.require_gpu_f32("gt_depth", gt_depth)
+    dev = rays_o.device
+    gd = _c(gt_depth.detach().reshape(-1))
+    R = gd.shape[0]
+    S = n_strat + n_imp
+    lib = _hip.lib()
+    if rand is None:
+        t_rand = torch.rand(R, S, device=dev) if perturb else None
+        t_uni = torch.rand(R, n_strat, device=dev) if perturb else None
+        u = torch.rand(R, n_imp, device=dev)
+    else:
+        t_rand, t_uni, u = (None if t is None else _c(t) for t in rand)
+    z = torch.empty(R, S, device=dev)
+    t_free, t_surf = linspace01(n_strat, dev), linspace01(n_imp, dev)
+    with torch.cuda.device(dev):
+        st = _hip.stream_handle(dev)
+        _hip.check(lib.eslam_sample_z(_hip.ptr(gd), R, n_strat, n_imp, float(truncation), _hip.ptr(t_free),
+                                      _hip.ptr(t_surf), _hip.ptr(t_rand), _hip.ptr(z), st), "eslam_sample_z")
+        if u is not None:
+            ro, rd = _c(rays_o.detach()), _c(rays_d.detach())
+            arr, _ = _hip.make_planes(tuple([p.detach() for p in grp] for grp in all_planes))
+            dec, keep = _hip.make_decoders([p.detach() for p in decoder_params(decoders)],
+                                           beta_tensor(decoders.beta, dev).detach())
+            _hip.check(lib.eslam_importance_z(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(ro),
+                                              _hip.ptr(rd), _hip.ptr(gd), R, n_strat, n_imp, _hip.ptr(t_free),
+                                              _hip.ptr(t_uni), _hip.ptr(u), _hip.ptr(z), st), "eslam_importance_z")
+    return z
+
+
+class MappingLossFn(torch.autograd.Function):
+    """loss = MappingLossFn.apply(depth, rgb, sdf, z_vals, gt_depth, gt_color, truncation, weights5, ray_mask)
+
+    Fused restatement of Mapper.py:110-144,337-346 (ray_mask None) / Tracker.py:114-148,197-204 (ray_mask given)."""
+
+    @staticmethod
+    def forward(ctx, depth, rgb, sdf, z_vals, gt_depth, gt_color, truncation, weights5, ray_mask):
+        for n, t in (("depth", depth), ("rgb", rgb), ("sdf", sdf), ("z_vals", z_vals), ("gt_depth", gt_depth),
+                     ("gt_color", gt_color)):
+            _hip.require_gpu_f32(n, t)
+        dev = depth.device
+        R, S = sdf.shape
+        args = [_c(t.detach()) for t in (depth, rgb, sdf, z_vals, gt_depth, gt_color)]
+        if ray_mask is not None:
+            ray_mask = _c(ray_mask.to(torch.uint8))
+        loss = torch.empty(1, device=dev)
+        g_depth = torch.empty(R, device=dev)
+        g_rgb = torch.empty(R, 3, device=dev)
+        g_sdf = torch.empty(R, S, device=dev)
+        scratch = torch.empty(16, device=dev)
+        w = (ctypes.c_float * 5)(*[float(v) for v in weights5])
+        with torch.cuda.device(dev):
+            _hip.check(_hip.lib().eslam_mapping_loss(*[_hip.ptr(t) for t in args], R, S, float(truncation), w, 0,
+                                                     _hip.ptr(ray_mask), _hip.ptr(loss), _hip.ptr(g_depth),
+                                                     _hip.ptr(g_rgb), _hip.ptr(g_sdf), _hip.ptr(scratch),
+                                                     _hip.stream_handle(dev)), "eslam_mapping_loss")
+        ctx.save_for_backward(g_depth, g_rgb, g_sdf)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        g_depth, g_rgb, g_sdf = ctx.saved_tensors
+        return g_depth * g, g_rgb * g, g_sdf * g, None, None, None, None, None, None

@@ -1,0 +1,63 @@
+"""Renderer: same constructor, attributes and methods as reference src/utils/Renderer.py:26-204, running on the
+fused HIP kernels.  Holds only Python scalars and the bound tensor, so it pickles into the reference's tracker
+and mapper processes (src/ESLAM.py:246-260); the native library is loaded lazily in each process.
+"""
+import torch
+
+from ... import ops
+from ..common import get_rays
+
+
+class Renderer(object):
+    def __init__(self, cfg, eslam, ray_batch_size=10000):
+        # Renderer.py:34-44
+        self.ray_batch_size = ray_batch_size
+        self.perturb = cfg['rendering']['perturb']
+        self.n_stratified = cfg['rendering']['n_stratified']
+        self.n_importance = cfg['rendering']['n_importance']
+        self.scale = cfg['scale']
+        self._bound6 = ops.bound_to_host(eslam.bound)        # host copy: no device sync per call
+        self.bound = eslam.bound.to(eslam.device, non_blocking=True)
+        self.H, self.W, self.fx, self.fy, self.cx, self.cy = eslam.H, eslam.W, eslam.fx, eslam.fy, eslam.cx, eslam.cy
+
+    def render_batch_ray(self, all_planes, decoders, rays_d, rays_o, device, truncation, gt_depth=None, _rand=None):
+        """Renderer.py:63-147.  NB argument order (rays_d, rays_o).  Returns depth [R], rgb [R,3], sdf [R,S],
+        z_vals [R,S].  `_rand` (tests only) injects the three uniform tensors instead of drawing them."""
+        n_rays = rays_o.shape[0]
+        S = self.n_stratified + self.n_importance
+        if gt_depth is None:
+            # the reference dereferences gt_depth unconditionally (Renderer.py:91)
+            raise AttributeError("'NoneType' object has no attribute 'reshape'")
+        if n_rays == 0:
+            e = rays_o.new_empty
+            return e(0), e(0, 3), e(0, S), e(0, S)
+        z_vals = ops.sample_z(rays_o, rays_d, gt_depth, all_planes, decoders, self._bound6, truncation,
+                              self.n_stratified, self.n_importance, self.perturb, _rand)
+        flat_planes = [p for grp in all_planes for p in grp]
+        beta = ops.beta_tensor(decoders.beta, rays_o.device)
+        # pts are normalised with decoders.bound (decoders.py:138), the importance sampler uses renderer.bound
+        bound6 = ops.bound_to_host(decoders.bound)
+        depth, rgb, sdf = ops.RenderFn.apply(rays_o, rays_d, z_vals, bound6, beta, *flat_planes,
+                                             *ops.decoder_params(decoders))
+        return depth, rgb, sdf, z_vals
+
+    def sdf2alpha(self, sdf, beta=10):
+        """Renderer.py:149-153 (kept for callers; the kernels fuse it)."""
+        return 1. - torch.exp(-beta * torch.sigmoid(-sdf * beta))
+
+    def render_img(self, all_planes, decoders, c2w, truncation, device, gt_depth=None):
+        """Renderer.py:155-204: all H*W rays in chunks of ray_batch_size, no grad; depth returned as float64."""
+        with torch.no_grad():
+            H, W = self.H, self.W
+            rays_o, rays_d = get_rays(H, W, self.fx, self.fy, self.cx, self.cy, c2w, device)
+            rays_o = rays_o.reshape(-1, 3)
+            rays_d = rays_d.reshape(-1, 3)
+            gt_depth = gt_depth.reshape(-1)
+            depth_list, color_list = [], []
+            for i in range(0, rays_d.shape[0], self.ray_batch_size):
+                ret = self.render_batch_ray(all_planes, decoders, rays_d[i:i + self.ray_batch_size],
+                                            rays_o[i:i + self.ray_batch_size], device, truncation,
+                                            gt_depth=gt_depth[i:i + self.ray_batch_size])
+                depth_list.append(ret[0].double())
+                color_list.append(ret[1])
+            return torch.cat(depth_list, 0).reshape(H, W), torch.cat(color_list, 0).reshape(H, W, 3)

@@ -1,0 +1,281 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI, via the reference-shaped Python API) against
+  (1) the committed golden fixtures = outputs of the reference itself, and
+  (2) the CPU oracle on the same inputs,
+plus size-independent properties at BASELINE.json's full sizes.
+
+Tolerance (north_star): 1e-4 relative, float32 - relative to the largest magnitude of the compared tensor.
+z_vals of rays with depth are required to be BIT-EXACT (the sampler reproduces the reference's rounding).
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as hp
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def build(fx, channels_last=True, planes_grad=True, dec_grad=True):
+    """Renderer + Decoders + planes on the GPU for a fixture."""
+    from myslam_amd.src.networks.decoders import Decoders
+    from myslam_amd.src.utils.Renderer import Renderer
+    dev = _dev()
+    sc, planes = hp.scene_and_planes(fx, device=dev, channels_last=channels_last)
+    if planes_grad:
+        planes = tuple([torch.nn.Parameter(p) for p in grp] for grp in planes)   # as Mapper.py:254-266
+    dec = Decoders(learnable_beta=bool(fx["beta_is_param"]))
+    sd = {k[6:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("param:")}
+    dec.load_state_dict(sd)
+    dec = dec.to(dev)
+    dec.bound = sc.bound                                   # CPU tensor, as reference ESLAM.py:173
+    for p in dec.parameters():
+        p.requires_grad_(dec_grad)
+    cfg = sc.cfg(perturb=bool(fx["perturb"]))
+    cfg["rendering"]["n_stratified"] = int(fx["n_stratified"])
+    cfg["rendering"]["n_importance"] = int(fx["n_importance"])
+    eslam = SimpleNamespace(bound=sc.bound, device=dev, H=sc.H, W=sc.W, fx=sc.fx, fy=sc.fy, cx=sc.cx, cy=sc.cy)
+    return sc, planes, dec, Renderer(cfg, eslam)
+
+
+def run_hip(fx, channels_last=True, rays_grad=True, fused_loss=False):
+    from oracle import eslam_oracle as orc
+    dev = _dev()
+    sc, planes, dec, renderer = build(fx, channels_last)
+    t_rand, t_uni, u = hp.rand_inputs(fx)
+    rand = tuple(None if t is None else t.to(dev) for t in (t_rand, t_uni, u))
+    ro = torch.from_numpy(fx["rays_o"]).to(dev).requires_grad_(rays_grad)
+    rd = torch.from_numpy(fx["rays_d"]).to(dev).requires_grad_(rays_grad)
+    gd = torch.from_numpy(fx["gt_depth"]).to(dev)
+    gc = torch.from_numpy(fx["gt_color"]).to(dev)
+    tr = float(fx["truncation"])
+    depth, color, sdf, z = renderer.render_batch_ray(planes, dec, rd, ro, dev, tr, gt_depth=gd, _rand=rand)
+    kind = str(fx["loss_kind"])
+    if fused_loss:
+        from myslam_amd import losses
+        loss = (losses.mapping_loss if kind == "mapping" else losses.tracking_loss)(depth, color, sdf, z, gd, gc, tr)
+    else:   # the oracle's torch-op loss runs fine on GPU tensors: it is only the caller-side loss here
+        loss = (orc.mapping_loss if kind == "mapping" else orc.tracking_loss)(depth, color, sdf, z, gd, gc, tr)
+    loss.backward()
+    torch.cuda.synchronize()
+    return dict(depth=depth, color=color, sdf=sdf, z=z, loss=loss, ro=ro, rd=rd, dec=dec, planes=planes)
+
+
+def check_against_fixture(fx, r, rtol=RTOL):
+    pr = fx["probe"]
+    has = fx["gt_depth"][pr] > 0
+    z = r["z"].detach().cpu().numpy()[pr]
+    assert np.array_equal(z[has], fx["z_vals"][has]), "z_vals of rays with depth must be bit-exact"
+    if (~has).any():
+        assert hp.rel_err(z[~has], fx["z_vals"][~has]) <= rtol
+    assert hp.rel_err(r["sdf"].detach().cpu().numpy()[pr], fx["sdf"]) <= rtol
+    assert hp.rel_err(r["depth"].detach().cpu().numpy()[pr], fx["depth"]) <= rtol
+    assert hp.rel_err(r["color"].detach().cpu().numpy()[pr], fx["color"]) <= rtol
+    assert abs(float(r["sdf"].double().sum()) - float(fx["sdf_sum"])) <= rtol * float(r["sdf"].abs().double().sum())
+    assert abs(float(r["loss"]) - float(fx["loss"])) <= rtol * abs(float(fx["loss"]))
+    for k, p in r["dec"].named_parameters():
+        assert p.grad is not None, k
+        assert hp.rel_err(p.grad.cpu().numpy(), fx["grad:" + k]) <= rtol, k
+    assert hp.rel_err(r["ro"].grad.cpu().numpy()[pr], fx["g_rays_o"]) <= rtol
+    assert hp.rel_err(r["rd"].grad.cpu().numpy()[pr], fx["g_rays_d"]) <= rtol
+    assert hp.rel_err(r["ro"].grad.double().sum(0).cpu().numpy(), fx["g_rays_o_sum"]) <= rtol
+    hp.check_plane_probes(fx, [p.grad for p in hp.flat_planes(r["planes"])], rtol=rtol)
+
+
+@pytest.mark.parametrize("case", hp.RENDER_CASES)
+def test_render_fwd_bwd_matches_reference_fixture(case):
+    fx = hp.load(case)
+    check_against_fixture(fx, run_hip(fx))
+
+
+@pytest.mark.parametrize("case", ["room0_200x32", "room0_200x40_zero15"])
+def test_render_nchw_planes(case):
+    """Planes exactly as the reference allocates them (NCHW-contiguous) go through the strided kernels."""
+    fx = hp.load(case)
+    r = run_hip(fx, channels_last=False)
+    check_against_fixture(fx, r)
+    for p in hp.flat_planes(r["planes"]):
+        assert p.grad.stride() == p.stride()
+
+
+@pytest.mark.parametrize("case", ["room0_200x32", "room0_200x40_zero15", "room0_200x40_tracking"])
+def test_fused_loss_matches(case):
+    fx = hp.load(case)
+    check_against_fixture(fx, run_hip(fx, fused_loss=True))
+
+
+@pytest.mark.parametrize("case", ["room0_200x32", "room0_200x40_zero15"])
+def test_full_gradients_vs_oracle(case):
+    """Every element of every gradient (not only fixture probes) against autograd over the float64 oracle."""
+    from tests.test_oracle_golden import run_oracle
+    fx = hp.load(case)
+    r = run_hip(fx)
+    o = run_oracle(fx, torch.float64)
+    assert hp.rel_err(r["sdf"].detach().cpu().numpy(), o["sdf"].detach().numpy()) <= RTOL
+    assert hp.rel_err(r["depth"].detach().cpu().numpy(), o["depth"].detach().numpy()) <= RTOL
+    assert hp.rel_err(r["color"].detach().cpu().numpy(), o["color"].detach().numpy()) <= RTOL
+    for a, b in zip(hp.flat_planes(r["planes"]), hp.flat_planes(o["planes"])):
+        assert hp.rel_err(a.grad.cpu().numpy(), b.grad.numpy()) <= RTOL
+    assert hp.rel_err(r["ro"].grad.cpu().numpy(), o["ro"].grad.numpy()) <= RTOL
+    assert hp.rel_err(r["rd"].grad.cpu().numpy(), o["rd"].grad.numpy()) <= RTOL
+    if bool(fx["beta_is_param"]):
+        assert hp.rel_err(r["dec"].beta.grad.cpu().numpy(), o["beta"].grad.numpy()) <= RTOL
+
+
+def test_tracking_mode_pose_gradients_only():
+    """Tracker.py:111-112,222-232: decoders frozen, planes detached - only rays carry gradient."""
+    fx = hp.load("room0_200x40_tracking")
+    dev = _dev()
+    sc, planes, dec, renderer = build(fx, planes_grad=False, dec_grad=False)
+    t_rand, _, _ = hp.rand_inputs(fx)
+    ro = torch.from_numpy(fx["rays_o"]).to(dev).requires_grad_(True)
+    rd = torch.from_numpy(fx["rays_d"]).to(dev).requires_grad_(True)
+    gd = torch.from_numpy(fx["gt_depth"]).to(dev)
+    gc = torch.from_numpy(fx["gt_color"]).to(dev)
+    from myslam_amd import losses
+    depth, color, sdf, z = renderer.render_batch_ray(planes, dec, rd, ro, dev, float(fx["truncation"]), gt_depth=gd,
+                                                     _rand=(t_rand.to(dev), None, None))
+    losses.tracking_loss(depth, color, sdf, z, gd, gc, float(fx["truncation"])).backward()
+    pr = fx["probe"]
+    assert hp.rel_err(ro.grad.cpu().numpy()[pr], fx["g_rays_o"]) <= RTOL
+    assert hp.rel_err(rd.grad.cpu().numpy()[pr], fx["g_rays_d"]) <= RTOL
+    assert all(p.grad is None for p in dec.parameters())
+
+
+def test_get_samples_and_get_rays():
+    from myslam_amd import scene as scn, synth
+    from myslam_amd.src import common
+    dev = _dev()
+    fx = hp.load("get_samples_room0_b3")
+    sc = scn.make_scene("room0")
+    b, n = int(fx["b"]), int(fx["n"])
+    H0, H1, W0, W1 = (int(v) for v in fx["window"])
+    call = fx["rand_calls"].tolist()[0].split(";")
+    idx = torch.from_numpy(synth.hash_randint(int(call[2]), (b * n,), int(call[1]))).to(dev)
+    depth_img = torch.from_numpy(np.stack([synth.depth_image(sc.H, sc.W, 20 + i) for i in range(b)])).to(dev)
+    color_img = torch.from_numpy(np.stack([synth.color_image(sc.H, sc.W, 30 + i) for i in range(b)])).to(dev)
+    c2ws = torch.from_numpy(fx["c2ws"]).to(dev).requires_grad_(True)
+    ro, rd, d, c = common.get_samples_at(idx, H0, H1, W0, W1, n, sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, c2ws,
+                                         depth_img, color_img)
+    assert np.array_equal(d.cpu().numpy(), fx["depth"]) and np.array_equal(c.cpu().numpy(), fx["color"])
+    assert np.array_equal(ro.detach().cpu().numpy(), fx["rays_o"])
+    assert hp.rel_err(rd.detach().cpu().numpy(), fx["rays_d"]) <= 1e-6
+    wo = torch.from_numpy(synth.hash_uniform(tuple(ro.shape), 61_000)).to(dev) - 0.5
+    wd = torch.from_numpy(synth.hash_uniform(tuple(rd.shape), 61_001)).to(dev) - 0.5
+    ((ro * wo).sum() + (rd * wd).sum()).backward()
+    assert hp.rel_err(c2ws.grad.cpu().numpy(), fx["g_c2ws"]) <= 1e-5
+    # the public entry draws its own indices: shapes, ranges, determinism under manual_seed
+    torch.manual_seed(1)
+    a = common.get_samples(H0, H1, W0, W1, n, sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, c2ws.detach(), depth_img,
+                           color_img, dev)
+    torch.manual_seed(1)
+    b2 = common.get_samples(H0, H1, W0, W1, n, sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, c2ws.detach(), depth_img,
+                            color_img, dev)
+    assert a[0].shape == (b * n, 3) and a[2].shape == (b * n,) and all(torch.equal(x, y) for x, y in zip(a, b2))
+    # whole-image rays
+    fr = hp.load("get_rays_room0")
+    ro_i, rd_i = common.get_rays(sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, torch.from_numpy(fr["c2w"]), dev)
+    assert ro_i.shape == (sc.H, sc.W, 3)
+    sel = fr["sel"]
+    assert hp.rel_err(ro_i.reshape(-1, 3).cpu().numpy()[sel], fr["rays_o"]) <= 1e-7
+    assert hp.rel_err(rd_i.reshape(-1, 3).cpu().numpy()[sel], fr["rays_d"]) <= 1e-6
+
+
+def test_decoders_forward_and_backward():
+    """Decoders.forward on free points incl. points outside the AABB (border clamp): fixture + oracle autograd."""
+    from myslam_amd import scene as scn
+    from myslam_amd.src.networks.decoders import Decoders
+    from oracle import eslam_oracle as orc
+    dev = _dev()
+    fx = hp.load("decoders_room0_points")
+    sc = scn.make_scene("room0")
+    planes = scn.synth_planes(sc, device=dev)
+    planes = tuple([p.requires_grad_(True) for p in grp] for grp in planes)
+    dec = Decoders()
+    dec.load_state_dict({k[6:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("param:")})
+    dec = dec.to(dev)
+    dec.bound = sc.bound
+    p = torch.from_numpy(fx["points"]).to(dev).requires_grad_(True)
+    raw = dec(p.reshape(40, 50, 3), all_planes=planes)        # keyword form used by Mesher.py:151
+    assert raw.shape == (40, 50, 4)
+    assert hp.rel_err(raw.detach().reshape(-1, 4).cpu().numpy(), fx["raw"]) <= RTOL
+    wts = torch.linspace(0.5, 1.5, raw.numel(), device=dev).reshape(raw.shape)
+    (raw * wts).sum().backward()
+    # oracle, float64
+    cp = scn.synth_planes(sc, dtype=torch.float64, channels_last=False)
+    cp = tuple([q.requires_grad_(True) for q in grp] for grp in cp)
+    params = hp.params_from(fx, dtype=torch.float64, requires_grad=True)
+    p64 = torch.from_numpy(fx["points"]).double().requires_grad_(True)
+    raw64 = orc.decode(p64, cp, params, sc.bound.double())
+    (raw64 * wts.cpu().double().reshape(-1, 4)).sum().backward()
+    assert hp.rel_err(p.grad.cpu().numpy(), p64.grad.numpy()) <= RTOL
+    for a, b in zip(hp.flat_planes(planes), hp.flat_planes(cp)):
+        assert hp.rel_err(a.grad.cpu().numpy(), b.grad.numpy()) <= RTOL
+    for k, t in dec.named_parameters():
+        if k != "beta":
+            assert hp.rel_err(t.grad.cpu().numpy(), params[k].grad.numpy()) <= RTOL, k
+    # get_raw_sdf on normalised coordinates, no-grad path (Renderer.py:124-125 style)
+    with torch.no_grad():
+        pn = torch.from_numpy(fx["p_nor"]).to(dev)
+        sdf = dec.get_raw_sdf(pn, planes)
+    assert hp.rel_err(sdf.cpu().numpy(), fx["raw"][:, 3]) <= RTOL
+
+
+def _bench_like(R, n_strat, n_imp, scene="room0", zero_frac=0.0, seed=0):
+    from myslam_amd import harness
+    return harness.make_workload(scene, R, n_strat, n_imp, device=_dev(), zero_frac=zero_frac, seed=seed)
+
+
+@pytest.mark.parametrize("cfg", [("room0", 4096, 56, 8, 0.0), ("scene0000", 8192, 88, 8, 0.1)])
+def test_full_size_properties(cfg):
+    """Size-independent properties at BASELINE.json sizes: sorted z, weights in [0,1] => depth inside the sampled
+    range and colour inside [0,1]; linearity of the backward pass in the upstream gradient; ray-shard equivalence
+    (1 shard == sum of 4 shards), which is exactly what the multi-GPU path relies on."""
+    scene, R, ns, ni, zf = cfg
+    wl = _bench_like(R, ns, ni, scene, zf)
+    dev = _dev()
+    out = wl.forward()
+    depth, color, sdf, z = out
+    assert torch.all(z[:, 1:] >= z[:, :-1]), "z_vals must be ascending"
+    assert torch.all(color >= 0) and torch.all(color <= 1 + 1e-6)
+    assert torch.all(depth >= torch.clamp(z[:, 0], max=0) - 1e-5) and torch.all(depth <= z[:, -1] + 1e-5)
+    assert torch.all(sdf.abs() <= 1)
+    # linearity: bwd(2 g) == 2 bwd(g)
+    g1 = wl.backward_with(out, scale=1.0)
+    g2 = wl.backward_with(wl.forward(), scale=2.0)
+    for a, b in zip(g1, g2):
+        assert hp.rel_err((2 * a).cpu().numpy(), b.cpu().numpy()) <= 2e-5
+    # shard equivalence
+    acc = None
+    for k in range(4):
+        gs = wl.backward_with(wl.forward(shard=(k, 4)), scale=1.0, shard=(k, 4))
+        acc = gs if acc is None else [x + y for x, y in zip(acc, gs)]
+    for a, b in zip(g1, acc):
+        assert hp.rel_err(a.cpu().numpy(), b.cpu().numpy()) <= RTOL
+
+
+def test_render_img_shapes_and_dtype():
+    from myslam_amd import harness
+    wl = _bench_like(64, 32, 8)
+    r = wl.renderer
+    r.H, r.W = 48, 64                      # small image, same intrinsics
+    gt = torch.full((48, 64), 1.5, device=_dev())
+    depth, color = r.render_img(wl.planes, wl.decoders, wl.c2w.to(_dev()), wl.truncation, _dev(), gt_depth=gt)
+    assert depth.dtype == torch.float64 and depth.shape == (48, 64) and color.shape == (48, 64, 3)
+    assert torch.isfinite(depth).all() and torch.isfinite(color).all()
+
+
+def test_cpu_tensors_fail_loudly():
+    fx = hp.load("room0_200x32")
+    sc, planes, dec, renderer = build(fx)
+    ro = torch.from_numpy(fx["rays_o"])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        renderer.render_batch_ray(planes, dec, ro, ro, "cpu", 0.06, gt_depth=torch.from_numpy(fx["gt_depth"]))
