@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Bench of the ESLAM rendering hot path on MI355X (contract: one JSON line on stdout from rank 0).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one mapping iteration minus the optimiser update: depth-guided sampling ->
+render_batch_ray forward -> mapping loss -> backward to the 12 planes and the decoders, on BASELINE.json configs[1]:
+synthetic Replica room0, 4096 rays x 64 samples (56 stratified + 8 surface), float32, inputs resident in HBM.
+With N > 1 every rank renders its own 4096 rays (weak scaling) and the iteration adds the two collectives of
+myslam_amd/parallel.py (16-float loss denominators, 27 MB gradient all-reduce over RCCL/xGMI).
+
+value = ray.samples/s of the whole job = N * R_eff * S / t_step, t_step = max over ranks of (wall time of K steps)/K.
+roofline = dominant kernel's ALGORITHMIC bytes per launch / its HIP-event-timed duration.
+cpu_baseline = the CPU oracle (a restatement of the reference's PyTorch path, pinned to the reference by
+tests/golden) timed on this box's host cores on the same workload - a reported baseline, not the target.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SCENE, RAYS, N_STRAT, N_IMP = "room0", 4096, 56, 8
+HBM_PEAK_GBS = 8000.0                 # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+# algorithmic bytes per ray.sample: 12 planes x 4 texels x 32 ch x 4 B gathered (fwd),
+# the same footprint scatter-added (bwd), + 16 B of per-sample I/O
+BYTES_FWD, BYTES_SCATTER = 6160, 6144
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-iters", type=int, default=20)
+    return ap.parse_args()
+
+
+def kernel_profile(step_fn, iters):
+    """Average HIP-event duration (ms) of every kernel of one step; events sit on the launch stream in the C-ABI."""
+    from myslam_amd import _hip
+    lib = _hip.lib()
+    sums, cnt = {}, {}
+    buf = (ctypes.c_float * 10)()
+    for _ in range(iters):
+        _hip.check(lib.eslam_profile_enable(1), "profile_enable")
+        step_fn()
+        torch.cuda.synchronize()
+        _hip.check(lib.eslam_profile_read(buf), "profile_read")
+        for i in range(10):
+            if buf[i] >= 0:
+                n = lib.eslam_profile_name(i).decode()
+                sums[n] = sums.get(n, 0.0) + buf[i]
+                cnt[n] = cnt.get(n, 0) + 1
+    lib.eslam_profile_enable(0)
+    return {k: sums[k] / cnt[k] for k in sums}
+
+
+def cpu_baseline(wl, budget_s=25.0, max_iters=5):
+    """Oracle on the host cores: forward + mapping loss + backward on the same rays / planes / decoders."""
+    from oracle import eslam_oracle as orc
+    torch.set_num_threads(os.cpu_count() or 1)
+    planes = tuple([p.detach().cpu().contiguous().requires_grad_(True) for p in grp] for grp in wl.planes)
+    params = {k: v.detach().cpu().requires_grad_(True) for k, v in wl.decoders.state_dict().items() if k != "beta"}
+    beta = wl.decoders.beta
+    beta = beta.detach().cpu().requires_grad_(True) if torch.is_tensor(beta) else float(beta)
+    ro, rd = wl.rays_o.detach().cpu(), wl.rays_d.detach().cpu()
+    gd, gc = wl.gt_depth.cpu(), wl.gt_color.cpu()
+    bound = wl.scene.bound
+    times = []
+    t_all = time.perf_counter()
+    for it in range(max_iters):
+        t_rand = torch.rand(wl.R, wl.S)
+        t0 = time.perf_counter()
+        depth, color, sdf, z = orc.render_batch_ray(planes, params, beta, bound, rd, ro, wl.truncation, gd,
+                                                    wl.n_strat, wl.n_imp, t_rand, None, None)
+        loss = orc.mapping_loss(depth, color, sdf, z, gd, gc, wl.truncation)
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+        for grp in planes:
+            for p in grp:
+                p.grad = None
+        if time.perf_counter() - t_all > budget_s:
+            break
+    t = sorted(times)[len(times) // 2]
+    return {"value": wl.R * wl.S / t, "unit": "ray.samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(times)} full iterations of the same {wl.R}x{wl.S} workload (median), torch CPU float32, "
+                      f"{t * 1e3:.0f} ms/iter"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from myslam_amd import harness
+    wl = harness.make_workload(SCENE, RAYS, N_STRAT, N_IMP, device=dev, seed=rank)
+    if world > 1:
+        from myslam_amd.parallel import ShardedMapper
+        mapper = ShardedMapper(wl)
+        step = mapper.step
+    else:
+        step = wl.step
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        r_tot = torch.tensor([wl.R], device=dev, dtype=torch.float64)
+        dist.all_reduce(r_tot)
+        total_rays = int(r_tot.item())
+    else:
+        total_rays = wl.R
+    ms_step = dt / args.steps * 1e3
+    value = total_rays * wl.S / (dt / args.steps)
+
+    out = None
+    if rank == 0:
+        prof = kernel_profile(step if world == 1 else wl.step, args.profile_iters)
+        n = wl.R * wl.S
+        alg = {"render_fwd_kernel": BYTES_FWD * n, "scatter_kernel": BYTES_SCATTER * n}
+        dom = max((k for k in prof if k in alg), key=lambda k: prof[k])
+        achieved = alg[dom] / (prof[dom] * 1e-3) / 1e9
+        other = [k for k in alg if k != dom][0]
+        out = {
+            "metric": "ray.samples/s (render+bwd)", "value": value, "unit": "ray.samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Replica room0 (synthetic), {RAYS} rays x {wl.S} samples ({N_STRAT}+{N_IMP}) per GPU, "
+                                   "mapping iteration: sample + render fwd + loss + bwd (planes+decoders), no optimiser",
+                       "rays_after_aabb_filter": wl.R, "samples_per_ray": wl.S, "plane_bytes": wl.scene.plane_bytes,
+                       "planes_layout": "channels_last", "parallelism": f"ray-sharded dp{world}"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg[dom], "avg_kernel_ms": prof[dom],
+                         "second_kernel": {"kernel": other, "avg_kernel_ms": prof.get(other),
+                                           "achieved": alg[other] / (prof[other] * 1e-3) / 1e9 if other in prof else None},
+                         "whole_step": {"algorithmic_bytes": 12304 * n, "achieved": 12304 * n / (ms_step * 1e-3) / 1e9,
+                                        "frac": 12304 * n / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+            "kernel_ms": {k: round(v, 4) for k, v in sorted(prof.items())},
+        }
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        # reported on rank 0 at N=1 only (a host-side baseline does not change with the GPU count)
+        out["cpu_baseline"] = cpu_baseline(wl) if (world == 1 and not args.no_cpu_baseline) else None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -165,6 +165,14 @@ int eslam_loss_grad(const float* depth, const float* rgb, const float* sdf, cons
                     const float* weights5_host, const uint8_t* ray_mask, const float* acc, float* loss,
                     float* g_depth, float* g_rgb, float* g_sdf, eslam_stream_t stream);
 
+/* Per-kernel device timing for bench.py's roofline line (HIP events recorded on the launch stream around each
+ * kernel while enabled; adds nothing to the launch path when disabled).  Usage: enable(1); run one iteration;
+ * synchronise the stream; read(ms) -> elapsed milliseconds of the LAST launch of each kernel, -1 if it did not run. */
+#define ESLAM_PROF_KERNELS 10
+int eslam_profile_enable(int on);
+int eslam_profile_read(float* ms_out);
+const char* eslam_profile_name(int kernel_id);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,9 @@ SIGNATURES = {
     "eslam_decode_bwd": (_i, [_PP, _DP, _BP, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "eslam_mapping_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _BP, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "eslam_loss_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp]),
+    "eslam_profile_enable": (_i, [_i]),
+    "eslam_profile_read": (_i, [_BP]),
+    "eslam_profile_name": (ctypes.c_char_p, [_i]),
     "eslam_loss_grad": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _BP, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 

@@ -60,3 +60,60 @@ int eslam_validate_planes(const eslam_plane_t* planes, int first, int count) {
     }
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// per-kernel timing with HIP events on the launch stream
+// ---------------------------------------------------------------------------------------------------------
+static bool g_prof_on = false;
+static hipEvent_t g_ev[ESLAM_PROF_KERNELS][2];
+static bool g_ev_made = false;
+static bool g_ev_used[ESLAM_PROF_KERNELS];
+static const char* const g_prof_names[ESLAM_PROF_KERNELS] = {
+    "render_fwd_kernel", "composite_bwd_kernel", "mlp_bwd_kernel", "dec_grad_reduce_kernel", "scatter_kernel",
+    "coord_bwd_kernel", "loss_reduce_kernel+loss_grad_kernel", "sample_z_kernel", "importance_z_kernel",
+    "decode_fwd_kernel"};
+
+void eslam_prof_begin(int id, hipStream_t st) {
+    if (!g_prof_on) return;
+    (void)hipEventRecord(g_ev[id][0], st);
+}
+
+void eslam_prof_end(int id, hipStream_t st) {
+    if (!g_prof_on) return;
+    (void)hipEventRecord(g_ev[id][1], st);
+    g_ev_used[id] = true;
+}
+
+extern "C" int eslam_profile_enable(int on) {
+    if (on && !g_ev_made) {
+        for (int i = 0; i < ESLAM_PROF_KERNELS; ++i)
+            for (int j = 0; j < 2; ++j)
+                if (hipEventCreate(&g_ev[i][j]) != hipSuccess) {
+                    eslam_set_error("eslam_profile_enable: hipEventCreate failed");
+                    return 2;
+                }
+        g_ev_made = true;
+    }
+    for (int i = 0; i < ESLAM_PROF_KERNELS; ++i) g_ev_used[i] = false;
+    g_prof_on = on != 0;
+    return 0;
+}
+
+extern "C" int eslam_profile_read(float* ms_out) {
+    if (!ms_out || !g_ev_made) {
+        eslam_set_error("eslam_profile_read: profiling was never enabled");
+        return 1;
+    }
+    for (int i = 0; i < ESLAM_PROF_KERNELS; ++i) {
+        ms_out[i] = -1.0f;
+        if (!g_ev_used[i]) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_ev[i][0], g_ev[i][1]) == hipSuccess) ms_out[i] = ms;
+        g_ev_used[i] = false;
+    }
+    return 0;
+}
+
+extern "C" const char* eslam_profile_name(int kernel_id) {
+    return (kernel_id >= 0 && kernel_id < ESLAM_PROF_KERNELS) ? g_prof_names[kernel_id] : "";
+}

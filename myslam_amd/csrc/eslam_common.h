@@ -132,6 +132,12 @@ __device__ __forceinline__ float4_t mfma16(float a, float b, float4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// per-kernel HIP-event timing (eslam_api.hip); PROF_* ids index eslam_profile_name()
+enum { PROF_RENDER_FWD = 0, PROF_COMPOSITE_BWD, PROF_MLP_BWD, PROF_DEC_REDUCE, PROF_SCATTER, PROF_COORD_BWD, PROF_LOSS,
+       PROF_SAMPLE_Z, PROF_IMPORTANCE_Z, PROF_DECODE_FWD };
+void eslam_prof_begin(int id, hipStream_t st);
+void eslam_prof_end(int id, hipStream_t st);
+
 // thread-local error string shared by the API translation units
 void eslam_set_error(const char* fmt, ...);
 int eslam_check_launch(const char* what);

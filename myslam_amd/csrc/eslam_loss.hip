@@ -156,9 +156,12 @@ extern "C" int eslam_mapping_loss(const float* depth, const float* rgb, const fl
         eslam_set_error("eslam_mapping_loss: memset failed");
         return 2;
     }
+    eslam_prof_begin(PROF_LOSS, (hipStream_t)stream);
     if (int rc = eslam_loss_reduce(depth, rgb, sdf, z_vals, gt_depth, gt_color, R, S, truncation, ray_mask,
                                    (float*)scratch, stream))
         return rc;
-    return eslam_loss_grad(depth, rgb, sdf, z_vals, gt_depth, gt_color, R, S, truncation, weights5_host, ray_mask,
-                           (const float*)scratch, loss, g_depth, g_rgb, g_sdf, stream);
+    const int rc = eslam_loss_grad(depth, rgb, sdf, z_vals, gt_depth, gt_color, R, S, truncation, weights5_host,
+                                   ray_mask, (const float*)scratch, loss, g_depth, g_rgb, g_sdf, stream);
+    eslam_prof_end(PROF_LOSS, (hipStream_t)stream);
+    return rc;
 }

@@ -8,6 +8,7 @@
 //                          order, merges consecutive samples that fall into the same texel cell in registers and
 //                          flushes 256-B-shaped float atomics (2 texels x 32 channels per wave instruction)
 //   coord_bwd_kernel       optional: gradient w.r.t. the sample position -> rays_o / rays_d (pose) or points
+#include <stdlib.h>
 #include "eslam_decode_tile.h"
 
 #define SLAB 1364          // floats per decoder per wave slab (rgb decoder needs 1363)
@@ -566,18 +567,23 @@ static Bound make_bound(const float* b6) {
 
 #define MLP_BWD_MAX_WG 512
 
+int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float* rays_o, const float* rays_d,
+                     const float* z_or_pts, int64_t R, int S, bool render, const float* g_feat, int* perm,
+                     hipStream_t st);
+int eslam_scatter_v2_init();
+
 static int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
 
-// workspace layout: g_o [n,4] | g_feat [n,128] | slabs [MLP_BWD_MAX_WG*4][2][SLAB]
+// workspace layout: g_o [n,4] | g_feat [n,128] | slabs [MLP_BWD_MAX_WG*4][2][SLAB] | ray order [n] (int)
 extern "C" int64_t eslam_bwd_workspace_bytes(int64_t n_points) {
     if (n_points < 0) return -1;
     return align256(n_points * 4 * 4) + align256(n_points * 128 * 4) +
-           align256((int64_t)MLP_BWD_MAX_WG * 4 * 2 * SLAB * 4);
+           align256((int64_t)MLP_BWD_MAX_WG * 4 * 2 * SLAB * 4) + align256(n_points * 4);
 }
 
 static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, const Bound& bnd, const float* rays_o,
                       const float* rays_d, const float* z_or_pts, int64_t R, int S, bool render, const float* feat,
-                      float* g_o, float* g_feat, float* slabs, float* g_dec, float* g_out_a, float* g_out_b,
+                      float* g_o, float* g_feat, float* slabs, int* perm, float* g_dec, float* g_out_a, float* g_out_b,
                       hipStream_t st) {
     const int64_t N = render ? R * S : R;
     PlaneSet ps;
@@ -587,9 +593,13 @@ static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, 
     // decoder MLP backward
     const int64_t ntiles = (N + 63) / 64;
     const int nwg = (int)((ntiles + 3) / 4 < MLP_BWD_MAX_WG ? (ntiles + 3) / 4 : MLP_BWD_MAX_WG);
+    eslam_prof_begin(PROF_MLP_BWD, st);
     hipLaunchKernelGGL(mlp_bwd_kernel, dim3(nwg, 2), dim3(256), 0, st, *dec, feat, g_o, N, g_feat, slabs);
+    eslam_prof_end(PROF_MLP_BWD, st);
     if (int rc = eslam_check_launch("mlp_bwd_kernel")) return rc;
+    eslam_prof_begin(PROF_DEC_REDUCE, st);
     hipLaunchKernelGGL(dec_grad_reduce_kernel, dim3((SLAB + 63) / 64, 2), dim3(256), 0, st, slabs, nwg * 4, g_dec);
+    eslam_prof_end(PROF_DEC_REDUCE, st);
     if (int rc = eslam_check_launch("dec_grad_reduce_kernel")) return rc;
 
     // plane gradients
@@ -602,13 +612,21 @@ static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, 
         eslam_set_error("plane gradients must be requested for all 12 planes or for none");
         return 1;
     }
-    if (any_grad) {
+    static const bool use_v1 = getenv("ESLAM_SCATTER_V1") != nullptr;     // A/B switch for profiling only
+    if (any_grad && !use_v1) {
+        if (int rc = eslam_scatter_v2_init()) return rc;
+        eslam_prof_begin(PROF_SCATTER, st);
+        if (int rc = eslam_scatter_v2(planes, bnd, rays_o, rays_d, z_or_pts, R, S, render, g_feat, perm, st)) return rc;
+        eslam_prof_end(PROF_SCATTER, st);
+    } else if (any_grad) {
+        eslam_prof_begin(PROF_SCATTER, st);
         if (render)
             hipLaunchKernelGGL((scatter_kernel<true>), dim3((unsigned)R), dim3(256), 0, st, ps, bnd, rays_o, rays_d,
                                z_or_pts, (int)R, S, g_feat);
         else
             hipLaunchKernelGGL((scatter_kernel<false>), dim3((unsigned)ntiles), dim3(256), 0, st, ps, bnd, rays_o,
                                rays_d, z_or_pts, (int)R, 64, g_feat);
+        eslam_prof_end(PROF_SCATTER, st);
         if (int rc = eslam_check_launch("scatter_kernel")) return rc;
     }
     // position gradients
@@ -618,11 +636,13 @@ static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, 
 #define LAUNCH(CLv, RD)                                                                                            \
     hipLaunchKernelGGL((coord_bwd_kernel<CLv, RD>), grid, block, 0, st, ps, bnd, rays_o, rays_d, z_or_pts, (int)R, \
                        S, g_feat, g_out_a, g_out_b)
+        eslam_prof_begin(PROF_COORD_BWD, st);
         if (cl && render) LAUNCH(true, true);
         else if (cl) LAUNCH(true, false);
         else if (render) LAUNCH(false, true);
         else LAUNCH(false, false);
 #undef LAUNCH
+        eslam_prof_end(PROF_COORD_BWD, st);
         if (int rc = eslam_check_launch("coord_bwd_kernel")) return rc;
     }
     return 0;
@@ -658,17 +678,20 @@ extern "C" int eslam_render_bwd(const eslam_plane_t* planes, const eslam_decoder
     float* g_o = (float*)ws;
     float* g_feat = (float*)(ws + align256(N * 16));
     float* slabs = (float*)(ws + align256(N * 16) + align256(N * 512));
+    int* perm = (int*)(ws + align256(N * 16) + align256(N * 512) + align256((int64_t)MLP_BWD_MAX_WG * 4 * 2 * SLAB * 4));
     const Bound bnd = make_bound(bound6_host);
 
     if (hipMemsetAsync(g_beta, 0, sizeof(float), st) != hipSuccess) {
         eslam_set_error("eslam_render_bwd: memset failed");
         return 2;
     }
+    eslam_prof_begin(PROF_COMPOSITE_BWD, st);
     hipLaunchKernelGGL(composite_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, st, z_vals, sdf, raw_rgb, dec->beta,
                        g_depth, g_rgb, g_sdf, R, S, g_o, g_beta);
+    eslam_prof_end(PROF_COMPOSITE_BWD, st);
     if (int rc = eslam_check_launch("composite_bwd_kernel")) return rc;
-    return bwd_common(planes, dec, bnd, rays_o, rays_d, z_vals, R, S, true, feat, g_o, g_feat, slabs, g_dec, g_rays_o,
-                      g_rays_d, st);
+    return bwd_common(planes, dec, bnd, rays_o, rays_d, z_vals, R, S, true, feat, g_o, g_feat, slabs, perm, g_dec,
+                      g_rays_o, g_rays_d, st);
 }
 
 extern "C" int eslam_decode_bwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
@@ -692,6 +715,6 @@ extern "C" int eslam_decode_bwd(const eslam_plane_t* planes, const eslam_decoder
     const Bound bnd = make_bound(bound6_host);
     hipLaunchKernelGGL(decode_act_bwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, raw, g_raw, N, g_o);
     if (int rc = eslam_check_launch("decode_act_bwd_kernel")) return rc;
-    return bwd_common(planes, dec, bnd, nullptr, nullptr, pts, N, 64, false, feat, g_o, g_feat, slabs, g_dec, g_pts,
-                      nullptr, st);
+    return bwd_common(planes, dec, bnd, nullptr, nullptr, pts, N, 64, false, feat, g_o, g_feat, slabs, nullptr, g_dec,
+                      g_pts, nullptr, st);
 }

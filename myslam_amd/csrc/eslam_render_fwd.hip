@@ -205,11 +205,13 @@ extern "C" int eslam_render_fwd(const eslam_plane_t* planes, const eslam_decoder
 #define LAUNCH(CLv, SV)                                                                                             \
     hipLaunchKernelGGL((render_fwd_kernel<CLv, SV>), grid, block, 0, st, ps, *dec, bnd, rays_o, rays_d, z_vals, R, \
                        S, depth, rgb, sdf, raw_rgb, feat)
+    eslam_prof_begin(PROF_RENDER_FWD, st);
     if (cl && save) LAUNCH(true, true);
     else if (cl) LAUNCH(true, false);
     else if (save) LAUNCH(false, true);
     else LAUNCH(false, false);
 #undef LAUNCH
+    eslam_prof_end(PROF_RENDER_FWD, st);
     return eslam_check_launch("render_fwd_kernel");
 }
 
@@ -236,6 +238,7 @@ extern "C" int eslam_decode_fwd(const eslam_plane_t* planes, const eslam_decoder
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(CLv, SO, SV) \
     hipLaunchKernelGGL((decode_fwd_kernel<CLv, SO, SV>), grid, block, 0, st, ps, *dec, bnd, pts, N, raw, feat)
+    eslam_prof_begin(PROF_DECODE_FWD, st);
     if (sdf_only) {
         if (cl) LAUNCH(true, true, false);
         else LAUNCH(false, true, false);
@@ -247,5 +250,6 @@ extern "C" int eslam_decode_fwd(const eslam_plane_t* planes, const eslam_decoder
         else LAUNCH(false, false, false);
     }
 #undef LAUNCH
+    eslam_prof_end(PROF_DECODE_FWD, st);
     return eslam_check_launch("decode_fwd_kernel");
 }

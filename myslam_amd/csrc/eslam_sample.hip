@@ -401,8 +401,10 @@ extern "C" int eslam_sample_z(const float* gt_depth, int R, int n_strat, int n_i
     // Renderer.py:97: (1.5 * truncation) and (3 * truncation) are Python-float products, cast to float32 by torch
     const float c15 = (float)(1.5 * truncation);
     const float c3 = (float)(3.0 * truncation);
+    eslam_prof_begin(PROF_SAMPLE_Z, (hipStream_t)stream);
     hipLaunchKernelGGL(sample_z_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, gt_depth, R, n_strat,
                        n_imp, c15, c3, t_free, t_surf, t_rand, z_vals);
+    eslam_prof_end(PROF_SAMPLE_Z, (hipStream_t)stream);
     return eslam_check_launch("sample_z_kernel");
 }
 
@@ -424,11 +426,13 @@ extern "C" int eslam_importance_z(const eslam_plane_t* planes, const eslam_decod
     for (int i = 0; i < NPL; ++i) ps.p[i] = planes[i < 6 ? i : i - 6];
     const Bound bnd = make_bound(bound6_host);
     dim3 grid((R + 3) / 4), block(256);
+    eslam_prof_begin(PROF_IMPORTANCE_Z, (hipStream_t)stream);
     if (eslam_planes_channels_last(planes, 0, 6))
         hipLaunchKernelGGL((importance_z_kernel<true>), grid, block, 0, (hipStream_t)stream, ps, *dec, bnd, rays_o,
                            rays_d, gt_depth, R, n_strat, n_imp, t_free, t_rand_uni, u, z_vals);
     else
         hipLaunchKernelGGL((importance_z_kernel<false>), grid, block, 0, (hipStream_t)stream, ps, *dec, bnd, rays_o,
                            rays_d, gt_depth, R, n_strat, n_imp, t_free, t_rand_uni, u, z_vals);
+    eslam_prof_end(PROF_IMPORTANCE_Z, (hipStream_t)stream);
     return eslam_check_launch("importance_z_kernel");
 }

@@ -56,6 +56,27 @@ def _split_planes(flat12):
     return tuple([flat12[2 * g], flat12[2 * g + 1]] for g in range(6))
 
 
+_grad_sink = None
+
+
+class grad_sink:
+    """Context manager: RenderFn.backward writes plane / decoder / beta gradients into the views of a
+    parallel.FlatGrads (params = 12 planes, 12 decoder tensors, [beta]) instead of fresh buffers, so a data-parallel
+    caller can all-reduce one flat buffer with no copy in between."""
+
+    def __init__(self, flat_grads):
+        self.fg = flat_grads
+
+    def __enter__(self):
+        global _grad_sink
+        self._prev, _grad_sink = _grad_sink, self.fg
+        return self.fg
+
+    def __exit__(self, *a):
+        global _grad_sink
+        _grad_sink = self._prev
+
+
 def _alloc_plane_grads(planes):
     """One flat zero buffer, 12 views with the planes' own strides (so autograd can adopt them without a copy
     and a multi-GPU caller can all-reduce the flat buffer)."""
@@ -126,12 +147,23 @@ class RenderFn(torch.autograd.Function):
         need_planes = any(need[5:17])
         need_rays = need[0] or need[1]
         grads = None
-        if need_planes:
+        sink = _grad_sink
+        if sink is not None:
+            sink.zero_()
+            grads = sink.views[:12]
+        elif need_planes:
             _, grads = _alloc_plane_grads(planes)
         arr, _ = _hip.make_planes(_split_planes([p.detach() for p in planes]), grads)
         dec, keep = _hip.make_decoders([p.detach() for p in params], beta.detach())
-        g_dec = torch.empty(_hip.N_DEC_PARAMS, device=dev)
-        g_beta = torch.empty(1, device=dev)
+        if sink is not None:
+            # the 12 decoder tensors follow the planes in the flat buffer in C-ABI order = the layout of g_dec
+            o = sink.offsets[12]
+            g_dec = sink.flat[o:o + _hip.N_DEC_PARAMS]
+            g_beta = sink.flat[sink.offsets[24]:sink.offsets[24] + 1] if len(sink.views) > 24 else \
+                torch.empty(1, device=dev)
+        else:
+            g_dec = torch.empty(_hip.N_DEC_PARAMS, device=dev)
+            g_beta = torch.empty(1, device=dev)
         g_ro = torch.empty(R, 3, device=dev) if need_rays else None
         g_rd = torch.empty(R, 3, device=dev) if need_rays else None
         ws = torch.empty(lib.eslam_bwd_workspace_bytes(R * S), dtype=torch.uint8, device=dev)
@@ -142,6 +174,9 @@ class RenderFn(torch.autograd.Function):
                                             _hip.ptr(feat), _hip.ptr(g_depth), _hip.ptr(g_rgb), _hip.ptr(g_sdf),
                                             _hip.ptr(g_dec), _hip.ptr(g_beta), _hip.ptr(g_ro), _hip.ptr(g_rd),
                                             _hip.ptr(ws), _hip.stream_handle(dev)), "eslam_render_bwd")
+        if sink is not None:
+            # the data-parallel caller owns .grad assignment (FlatGrads.assign): hand autograd nothing to accumulate
+            return (g_ro if need[0] else None, g_rd if need[1] else None) + (None,) * 27
         dec_grads = _split_dec_grads(g_dec)
         out = [g_ro if need[0] else None, g_rd if need[1] else None, None, None, g_beta if need[4] else None]
         out += [grads[i] if (need_planes and need[5 + i]) else None for i in range(12)]

@@ -1,0 +1,121 @@
+"""Ray-sharded data parallelism for mapping iterations - new, the reference is single-GPU.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Planes and decoders are replicated; the
+rays of an iteration are split across ranks; rays are independent in the forward pass, so the only exchange steps are
+
+  1. one all-reduce of ESLAM_LOSS_ACC = 16 floats (sizes of the loss's masked sets and their squared-error sums), so
+     that every rank scales its upstream gradients by the GLOBAL denominators of the reference's means
+     (src/Mapper.py:136-140,343,346) and the summed gradients equal those of the unsharded batch;
+  2. one all-reduce(sum) of ONE flat float32 buffer holding the 12 plane gradients, the 2692 decoder gradients and
+     beta's: 27.15 MB for room0, 70.5 MB for scene0000.
+
+Identical optimiser steps on every rank then keep the replicas in sync without a broadcast.
+The flat buffer is also what RenderFn.backward scatters into (ops.grad_sink), so no copy sits between the backward
+kernels and the collective.  Tracking (pose-only, needs a global median) is not sharded: "replicas only".
+"""
+import torch
+import torch.distributed as dist
+
+from . import _hip, ops
+
+
+def shard_slice(n, rank, world):
+    """Contiguous shard [lo, hi) of n rays for `rank`; the shards of all ranks tile [0, n) exactly."""
+    per = (n + world - 1) // world
+    lo = min(n, rank * per)
+    return lo, min(n, lo + per)
+
+
+class FlatGrads:
+    """One flat buffer + per-parameter views with the parameters' own shapes and strides."""
+
+    def __init__(self, params, extra=0):
+        self.params = list(params)
+        dev = self.params[0].device
+        sizes = [p.numel() for p in self.params]
+        self.flat = torch.zeros(sum(sizes) + extra, device=dev, dtype=torch.float32)
+        self.views, self.offsets, off = [], [], 0
+        for p, n in zip(self.params, sizes):
+            self.offsets.append(off)
+            dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+            if not dense:
+                raise RuntimeError("FlatGrads needs dense parameters")
+            self.views.append(self.flat[off:off + n].as_strided(p.shape, p.stride()))
+            off += n
+        self.offsets.append(off)
+        self.extra = self.flat[off:]
+
+    def zero_(self):
+        self.flat.zero_()
+
+    def all_reduce(self, group=None, async_op=False):
+        return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+    def assign(self):
+        """Point every parameter's .grad at its view (after the collective)."""
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+
+class ShardedLossFn(torch.autograd.Function):
+    """mapping_loss with global denominators: reduce phase -> all-reduce of the accumulators -> gradient phase."""
+
+    @staticmethod
+    def forward(ctx, depth, rgb, sdf, z_vals, gt_depth, gt_color, truncation, weights5, group):
+        import ctypes
+        dev = depth.device
+        R, S = sdf.shape
+        lib = _hip.lib()
+        args = [t.detach().contiguous() for t in (depth, rgb, sdf, z_vals, gt_depth, gt_color)]
+        acc = torch.zeros(16, device=dev)
+        loss = torch.empty(1, device=dev)
+        g_depth = torch.empty(R, device=dev)
+        g_rgb = torch.empty(R, 3, device=dev)
+        g_sdf = torch.empty(R, S, device=dev)
+        w = (ctypes.c_float * 5)(*[float(v) for v in weights5])
+        ptrs = [_hip.ptr(t) for t in args]
+        with torch.cuda.device(dev):
+            _hip.check(lib.eslam_loss_reduce(*ptrs, R, S, float(truncation), None, _hip.ptr(acc),
+                                             _hip.stream_handle(dev)), "eslam_loss_reduce")
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+        with torch.cuda.device(dev):
+            _hip.check(lib.eslam_loss_grad(*ptrs, R, S, float(truncation), w, None, _hip.ptr(acc), _hip.ptr(loss),
+                                           _hip.ptr(g_depth), _hip.ptr(g_rgb), _hip.ptr(g_sdf),
+                                           _hip.stream_handle(dev)), "eslam_loss_grad")
+        ctx.save_for_backward(g_depth, g_rgb, g_sdf)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        g_depth, g_rgb, g_sdf = ctx.saved_tensors
+        return g_depth * g, g_rgb * g, g_sdf * g, None, None, None, None, None, None
+
+
+class ShardedMapper:
+    """Drives one ray-sharded mapping iteration on this rank's shard (a harness.Workload holding this rank's rays)."""
+
+    def __init__(self, workload, group=None):
+        from . import losses
+        self.wl = workload
+        self.group = group
+        self.weights = losses.MAPPING_W
+        self.params = workload.plane_list + ops.decoder_params(workload.decoders)
+        beta = workload.decoders.beta
+        self.has_beta = torch.is_tensor(beta)
+        if self.has_beta:
+            self.params = self.params + [beta]
+        self.grads = FlatGrads(self.params)
+
+    def step(self):
+        wl = self.wl
+        for p in self.params:
+            p.grad = None
+        with ops.grad_sink(self.grads):
+            depth, color, sdf, z = wl.renderer.render_batch_ray(wl.planes, wl.decoders, wl.rays_d, wl.rays_o, wl.device,
+                                                                wl.truncation, gt_depth=wl.gt_depth)
+            loss = ShardedLossFn.apply(depth, color, sdf, z, wl.gt_depth, wl.gt_color, wl.truncation, self.weights,
+                                       self.group)
+            loss.backward()
+        self.grads.all_reduce(self.group)
+        self.grads.assign()
+        return loss

@@ -1,0 +1,16 @@
+"""Scatter experiments on the GPU box: time + table statistics for the settings given through ESLAM_SC_* env vars."""
+import ctypes, os, sys, time, torch
+sys.path.insert(0, '.')
+from myslam_amd import harness, _hip
+dev = torch.device('cuda:0')
+wl = harness.make_workload('room0', 4096, 56, 8, device=dev)
+lib = _hip.lib()
+buf = (ctypes.c_float * 10)()
+for _ in range(3): wl.step()
+torch.cuda.synchronize()
+ts = []
+for _ in range(10):
+    lib.eslam_profile_enable(1); wl.step(); torch.cuda.synchronize(); lib.eslam_profile_read(buf); ts.append(buf[4])
+lib.eslam_profile_enable(0)
+env = {k: v for k, v in os.environ.items() if k.startswith('ESLAM_SC')}
+print(env, 'scatter ms median %.4f' % sorted(ts)[5], 'all kernels ms:', [round(x, 4) for x in buf])
