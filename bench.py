@@ -67,7 +67,9 @@ def kernel_profile(step_fn, iters):
 def cpu_baseline(wl, budget_s=25.0, max_iters=5):
     """Oracle on the host cores: forward + mapping loss + backward on the same rays / planes / decoders."""
     from oracle import eslam_oracle as orc
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box gives a 1-GPU job a 16-CPU share of a 256-thread host: more torch threads than that oversubscribe
+    ncpu = min(len(os.sched_getaffinity(0)), int(os.environ.get("BENCH_CPU_THREADS", "16")))
+    torch.set_num_threads(max(1, ncpu))
     planes = tuple([p.detach().cpu().contiguous().requires_grad_(True) for p in grp] for grp in wl.planes)
     params = {k: v.detach().cpu().requires_grad_(True) for k, v in wl.decoders.state_dict().items() if k != "beta"}
     beta = wl.decoders.beta

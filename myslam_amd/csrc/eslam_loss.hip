@@ -30,12 +30,13 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restric
                                                           const float* __restrict__ gt_color,
                                                           const uint8_t* __restrict__ ray_mask, int R, int S, const Trunc tr,
                                                           float* __restrict__ acc) {
+    // grid-stride over rays: the 10 accumulators share one cache line, and same-line float atomics serialise at the
+    // memory side (~12 ns each), so the number of workgroups - not of rays - sets the cost of the final adds
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ray = blockIdx.x * 4 + wave;
     float v[A_COUNT];
 #pragma unroll
     for (int k = 0; k < A_COUNT; ++k) v[k] = 0.0f;
-    if (ray < R) {
+    for (int ray = blockIdx.x * 4 + wave; ray < R; ray += gridDim.x * 4) {
         const float d = gt_depth[ray];
         const bool m = ray_mask ? (ray_mask[ray] != 0) : (d > 0.0f);
         const bool mc = ray_mask ? m : true;
@@ -48,9 +49,9 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restric
                 else if (reg == 1) { v[A_N_CENTER] += 1.0f; const float e = (z + sd * tr.t) - d; v[A_S_CENTER] += e * e; }
                 else if (reg == 2) { v[A_N_TAIL] += 1.0f; const float e = (z + sd * tr.t) - d; v[A_S_TAIL] += e * e; }
             }
-            if (lane == 0) { const float e = d - depth[ray]; v[A_N_DEPTH] = 1.0f; v[A_S_DEPTH] = e * e; }
+            if (lane == 0) { const float e = d - depth[ray]; v[A_N_DEPTH] += 1.0f; v[A_S_DEPTH] += e * e; }
         }
-        if (mc && lane < 3) { const float e = gt_color[3 * ray + lane] - rgb[3 * ray + lane]; v[A_S_COLOR] = e * e; v[A_N_COLOR] = 1.0f; }
+        if (mc && lane < 3) { const float e = gt_color[3 * ray + lane] - rgb[3 * ray + lane]; v[A_S_COLOR] += e * e; v[A_N_COLOR] += 1.0f; }
     }
     __shared__ float red[4][A_COUNT];
 #pragma unroll
@@ -123,7 +124,8 @@ extern "C" int eslam_loss_reduce(const float* depth, const float* rgb, const flo
         eslam_set_error("eslam_loss_reduce: null accumulator");
         return 1;
     }
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, depth, rgb, sdf, z_vals,
+    const int nwg = (R + 3) / 4 < 256 ? (R + 3) / 4 : 256;
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, depth, rgb, sdf, z_vals,
                        gt_depth, gt_color, ray_mask, R, S, make_trunc(truncation), acc);
     return eslam_check_launch("loss_reduce_kernel");
 }

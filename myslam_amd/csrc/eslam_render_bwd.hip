@@ -31,9 +31,14 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
                                                             const float* __restrict__ g_rgb,
                                                             const float* __restrict__ g_sdf, int R, int S,
                                                             float* __restrict__ g_o, float* __restrict__ g_beta) {
+    // g_beta here is the per-workgroup partial buffer [gridDim.x]
+    // g_beta: every workgroup writes one partial sum (summed later by dec_grad_reduce_kernel).  One atomic per ray on
+    // the single address of g_beta serialises at the memory side: 4096 of them cost 50 us.
+    __shared__ float beta_part[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ray = blockIdx.x * 4 + wave;
-    if (ray >= R) return;
+    if (lane == 0) beta_part[wave] = 0.0f;
+    if (ray < R) {
     const float beta = beta_p[0];
     const float gd = g_depth ? g_depth[ray] : 0.0f;
     const float gr = g_rgb ? g_rgb[3 * ray + 0] : 0.0f;
@@ -114,7 +119,10 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restr
         }
     }
     const float tot = wave_sum(gbeta_acc);
-    if (lane == 0 && g_beta) atomicAdd(g_beta, tot);
+    if (lane == 0) beta_part[wave] = tot;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) g_beta[blockIdx.x] = (beta_part[0] + beta_part[1]) + (beta_part[2] + beta_part[3]);
 }
 
 // decode-mode variant: g_o = g_raw * activation'(raw)      (autograd of decoders.py:103,123)
@@ -307,20 +315,49 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const eslam_decoders_t dec
     }
 }
 
-// slabs [nrows][2][SLAB] -> g_dec (flat, order of eslam_decoders_t).  grid (ceil(SLAB/64), 2), block 256.
-__global__ __launch_bounds__(256) void dec_grad_reduce_kernel(const float* __restrict__ slabs, int nrows,
-                                                              float* __restrict__ g_dec) {
-    __shared__ float red[4][64];
+// slabs [nrows][2][SLAB] -> g_dec (flat, order of eslam_decoders_t).  grid (ceil(SLAB/64), 2), block 1024 =
+// 64 columns x 16 row groups; every thread keeps 8 independent loads in flight (the first version walked 512 rows
+// with one load outstanding and took 0.19 ms for 22 MB).
+#define RED_PARTS 16
+__global__ __launch_bounds__(1024) void dec_grad_reduce_kernel(const float* __restrict__ slabs, int nrows,
+                                                               float* __restrict__ g_dec,
+                                                               const float* __restrict__ beta_parts, int n_beta_parts,
+                                                               float* __restrict__ g_beta) {
+    __shared__ float red[RED_PARTS][64];
+    if (blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && beta_parts) {
+        // the last column block has only 20 live columns: it also sums the g_beta partials
+        __shared__ float bsum[16];
+        float a = 0.f;
+        for (int i = threadIdx.x; i < n_beta_parts; i += 1024) a += beta_parts[i];
+        a = wave_sum(a);
+        if ((threadIdx.x & 63) == 0) bsum[threadIdx.x >> 6] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+            for (int k = 0; k < 16; ++k) t += bsum[k];
+            g_beta[0] = t;
+        }
+    }
     const int d = blockIdx.y;
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int cl = threadIdx.x & 63;
+    const int col = blockIdx.x * 64 + cl;
     const int part = threadIdx.x >> 6;
-    float acc = 0.0f;
-    if (col < SLAB)
-        for (int row = part; row < nrows; row += 4) acc += slabs[((int64_t)row * 2 + d) * SLAB + col];
-    red[part][threadIdx.x & 63] = acc;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (col < SLAB) {
+        const float* src = slabs + (int64_t)d * SLAB + col;
+        int row = part;
+        for (; row + 7 * RED_PARTS < nrows; row += 8 * RED_PARTS) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += src[(int64_t)(row + u * RED_PARTS) * 2 * SLAB];
+        }
+        for (; row < nrows; row += RED_PARTS) acc[0] += src[(int64_t)row * 2 * SLAB];
+    }
+    red[part][cl] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     __syncthreads();
     if (part == 0 && col < SLAB) {
-        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < RED_PARTS; ++k) v += red[k][cl];
         const int nout = d ? 3 : 1;
         // slab offset -> flat offset inside the decoder's parameter block
         int dst = -1;
@@ -574,17 +611,22 @@ int eslam_scatter_v2_init();
 
 static int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
 
-// workspace layout: g_o [n,4] | g_feat [n,128] | slabs [MLP_BWD_MAX_WG*4][2][SLAB] | ray order [n] (int)
+// workspace layout: g_o [n,4] | g_feat [n,128] | slabs [MLP_BWD_MAX_WG*4][2][SLAB] + g_beta partials [n/4 + 1] |
+//                   ray order [n] (int)
+static int64_t slab_region_bytes(int64_t n_points) {
+    return ((int64_t)MLP_BWD_MAX_WG * 4 * 2 * SLAB + n_points / 4 + 1) * 4;
+}
+
 extern "C" int64_t eslam_bwd_workspace_bytes(int64_t n_points) {
     if (n_points < 0) return -1;
     return align256(n_points * 4 * 4) + align256(n_points * 128 * 4) +
-           align256((int64_t)MLP_BWD_MAX_WG * 4 * 2 * SLAB * 4) + align256(n_points * 4);
+           align256(slab_region_bytes(n_points)) + align256(n_points * 4);
 }
 
 static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, const Bound& bnd, const float* rays_o,
                       const float* rays_d, const float* z_or_pts, int64_t R, int S, bool render, const float* feat,
                       float* g_o, float* g_feat, float* slabs, int* perm, float* g_dec, float* g_out_a, float* g_out_b,
-                      hipStream_t st) {
+                      const float* beta_parts, int n_beta_parts, float* g_beta, hipStream_t st) {
     const int64_t N = render ? R * S : R;
     PlaneSet ps;
     for (int i = 0; i < NPL; ++i) ps.p[i] = planes[i];
@@ -598,7 +640,8 @@ static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, 
     eslam_prof_end(PROF_MLP_BWD, st);
     if (int rc = eslam_check_launch("mlp_bwd_kernel")) return rc;
     eslam_prof_begin(PROF_DEC_REDUCE, st);
-    hipLaunchKernelGGL(dec_grad_reduce_kernel, dim3((SLAB + 63) / 64, 2), dim3(256), 0, st, slabs, nwg * 4, g_dec);
+    hipLaunchKernelGGL(dec_grad_reduce_kernel, dim3((SLAB + 63) / 64, 2), dim3(1024), 0, st, slabs, nwg * 4, g_dec,
+                       beta_parts, n_beta_parts, g_beta);
     eslam_prof_end(PROF_DEC_REDUCE, st);
     if (int rc = eslam_check_launch("dec_grad_reduce_kernel")) return rc;
 
@@ -678,20 +721,19 @@ extern "C" int eslam_render_bwd(const eslam_plane_t* planes, const eslam_decoder
     float* g_o = (float*)ws;
     float* g_feat = (float*)(ws + align256(N * 16));
     float* slabs = (float*)(ws + align256(N * 16) + align256(N * 512));
-    int* perm = (int*)(ws + align256(N * 16) + align256(N * 512) + align256((int64_t)MLP_BWD_MAX_WG * 4 * 2 * SLAB * 4));
+    int* perm = (int*)(ws + align256(N * 16) + align256(N * 512) + align256(slab_region_bytes(N)));
     const Bound bnd = make_bound(bound6_host);
 
-    if (hipMemsetAsync(g_beta, 0, sizeof(float), st) != hipSuccess) {
-        eslam_set_error("eslam_render_bwd: memset failed");
-        return 2;
-    }
+    // g_beta partials: one float per composite_bwd workgroup, stored behind the decoder-gradient slabs
+    float* beta_parts = slabs + (int64_t)MLP_BWD_MAX_WG * 4 * 2 * SLAB;
+    const int n_beta_parts = (R + 3) / 4;
     eslam_prof_begin(PROF_COMPOSITE_BWD, st);
     hipLaunchKernelGGL(composite_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, st, z_vals, sdf, raw_rgb, dec->beta,
-                       g_depth, g_rgb, g_sdf, R, S, g_o, g_beta);
+                       g_depth, g_rgb, g_sdf, R, S, g_o, beta_parts);
     eslam_prof_end(PROF_COMPOSITE_BWD, st);
     if (int rc = eslam_check_launch("composite_bwd_kernel")) return rc;
     return bwd_common(planes, dec, bnd, rays_o, rays_d, z_vals, R, S, true, feat, g_o, g_feat, slabs, perm, g_dec,
-                      g_rays_o, g_rays_d, st);
+                      g_rays_o, g_rays_d, beta_parts, n_beta_parts, g_beta, st);
 }
 
 extern "C" int eslam_decode_bwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
@@ -716,5 +758,5 @@ extern "C" int eslam_decode_bwd(const eslam_plane_t* planes, const eslam_decoder
     hipLaunchKernelGGL(decode_act_bwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, raw, g_raw, N, g_o);
     if (int rc = eslam_check_launch("decode_act_bwd_kernel")) return rc;
     return bwd_common(planes, dec, bnd, nullptr, nullptr, pts, N, 64, false, feat, g_o, g_feat, slabs, nullptr, g_dec,
-                      g_pts, nullptr, st);
+                      g_pts, nullptr, nullptr, 0, nullptr, st);
 }

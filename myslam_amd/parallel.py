@@ -33,7 +33,7 @@ class FlatGrads:
         self.params = list(params)
         dev = self.params[0].device
         sizes = [p.numel() for p in self.params]
-        self.flat = torch.zeros(sum(sizes) + extra, device=dev, dtype=torch.float32)
+        self.flat = torch.zeros(sum(sizes) + extra, device=dev, dtype=self.params[0].dtype)
         self.views, self.offsets, off = [], [], 0
         for p, n in zip(self.params, sizes):
             self.offsets.append(off)
