@@ -22,7 +22,7 @@
 #include <stdlib.h>
 #include "eslam_decode_tile.h"
 
-#define SORT_MAX 16384
+#define SORT_MAX 8192
 
 // ---------------------------------------------------------------------------------------------------------
 // ray ordering
@@ -36,49 +36,103 @@ __device__ __forceinline__ unsigned spread3(unsigned v) {      // 10 bits -> eve
     return v;
 }
 
-// One workgroup sorts one chunk of up to SORT_MAX rays (bitonic network in LDS).  perm[chunk*SORT_MAX + i] = ray id.
+// One workgroup orders one chunk of up to SORT_MAX rays with a single-pass counting sort in LDS:
+// key = 15-bit Morton code of the point one metre along the ray, quantised inside the chunk's bounding box of such
+// points (rays of one camera: a patch of the unit sphere round its centre; several cameras: several patches, and
+// rays of nearby cameras with similar directions end up adjacent, which is what shares texels).  Order inside a cell
+// is arbitrary (atomic tickets).  perm[chunk*SORT_MAX + i] = ray id.  ~5 us for 4096 rays (a 78-stage bitonic
+// network in one workgroup took 62 us).
+#define ORD_BITS 5
+#define ORD_CELLS (1 << (3 * ORD_BITS))      // 32768 counters = 128 KB of LDS
+#define ORD_PER_THREAD (SORT_MAX / 1024)
 __global__ __launch_bounds__(1024) void ray_order_kernel(const float* __restrict__ rays_o,
-                                                         const float* __restrict__ rays_d, int R, const Bound bnd,
+                                                         const float* __restrict__ rays_d, int R,
                                                          int* __restrict__ perm) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long skey[];      // (key << 32) | local index
+    extern __shared__ __attribute__((aligned(16))) unsigned hist[];       // [ORD_CELLS]
+    __shared__ float red[16][6];
+    __shared__ unsigned wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int base = blockIdx.x * SORT_MAX;
     const int n = min(SORT_MAX, R - base);
-    int npow = 1;
-    while (npow < n) npow <<= 1;
-    for (int i = threadIdx.x; i < npow; i += blockDim.x) {
-        unsigned long long kv = ~0ull;                                                // padding sorts to the end
+
+    float px[ORD_PER_THREAD], py[ORD_PER_THREAD], pz[ORD_PER_THREAD];
+    float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+#pragma unroll
+    for (int k = 0; k < ORD_PER_THREAD; ++k) {
+        const int i = tid + k * 1024;
+        px[k] = py[k] = pz[k] = 0.f;
         if (i < n) {
             const int ray = base + i;
             const float dx = rays_d[3 * ray], dy = rays_d[3 * ray + 1], dz = rays_d[3 * ray + 2];
             const float inv = rsqrtf(fmaxf(dx * dx + dy * dy + dz * dz, 1e-20f));
-            const unsigned qx = (unsigned)fminf(fmaxf((dx * inv + 1.0f) * 32.0f, 0.0f), 63.0f);
-            const unsigned qy = (unsigned)fminf(fmaxf((dy * inv + 1.0f) * 32.0f, 0.0f), 63.0f);
-            const unsigned qz = (unsigned)fminf(fmaxf((dz * inv + 1.0f) * 32.0f, 0.0f), 63.0f);
-            const unsigned dkey = spread3(qx) | (spread3(qy) << 1) | (spread3(qz) << 2);       // 18 bits
-            // origin cell (16 per axis over the scene bound): rays of different cameras never share a bundle prefix
-            const unsigned ox = (unsigned)fminf(fmaxf((rays_o[3 * ray] - bnd.lo[0]) / (bnd.hi[0] - bnd.lo[0]) * 16.0f, 0.0f), 15.0f);
-            const unsigned oy = (unsigned)fminf(fmaxf((rays_o[3 * ray + 1] - bnd.lo[1]) / (bnd.hi[1] - bnd.lo[1]) * 16.0f, 0.0f), 15.0f);
-            const unsigned oz = (unsigned)fminf(fmaxf((rays_o[3 * ray + 2] - bnd.lo[2]) / (bnd.hi[2] - bnd.lo[2]) * 16.0f, 0.0f), 15.0f);
-            const unsigned okey = spread3(ox) | (spread3(oy) << 1) | (spread3(oz) << 2);       // 12 bits
-            kv = ((unsigned long long)((okey << 18) | dkey) << 32) | (unsigned)i;
+            px[k] = rays_o[3 * ray] + dx * inv;
+            py[k] = rays_o[3 * ray + 1] + dy * inv;
+            pz[k] = rays_o[3 * ray + 2] + dz * inv;
+            lo[0] = fminf(lo[0], px[k]); hi[0] = fmaxf(hi[0], px[k]);
+            lo[1] = fminf(lo[1], py[k]); hi[1] = fmaxf(hi[1], py[k]);
+            lo[2] = fminf(lo[2], pz[k]); hi[2] = fmaxf(hi[2], pz[k]);
         }
-        skey[i] = kv;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], m, WAVE));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], m, WAVE));
+        }
+        if (lane == 0) { red[wave][a] = lo[a]; red[wave][3 + a] = hi[a]; }
+    }
+    for (int i = tid; i < ORD_CELLS; i += 1024) hist[i] = 0u;
+    __syncthreads();
+    float scale[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float l = red[0][a], h = red[0][3 + a];
+        for (int w = 1; w < 16; ++w) { l = fminf(l, red[w][a]); h = fmaxf(h, red[w][3 + a]); }
+        lo[a] = l;
+        scale[a] = (float)(1 << ORD_BITS) / fmaxf(h - l, 1e-6f);
+    }
+    unsigned key[ORD_PER_THREAD], ticket[ORD_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < ORD_PER_THREAD; ++k) {
+        const int i = tid + k * 1024;
+        key[k] = 0; ticket[k] = 0;
+        if (i < n) {
+            const unsigned qmax = (1u << ORD_BITS) - 1;
+            const unsigned qx = min((unsigned)fmaxf((px[k] - lo[0]) * scale[0], 0.f), qmax);
+            const unsigned qy = min((unsigned)fmaxf((py[k] - lo[1]) * scale[1], 0.f), qmax);
+            const unsigned qz = min((unsigned)fmaxf((pz[k] - lo[2]) * scale[2], 0.f), qmax);
+            key[k] = spread3(qx) | (spread3(qy) << 1) | (spread3(qz) << 2);
+            ticket[k] = atomicAdd(&hist[key[k]], 1u);
+        }
     }
     __syncthreads();
-    for (int k = 2; k <= npow; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < npow; i += blockDim.x) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const unsigned long long a = skey[i], b = skey[l];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { skey[i] = b; skey[l] = a; }
-                }
-            }
-            __syncthreads();
-        }
+    // exclusive scan of the counters: thread t owns counters [32t, 32t+32)
+    const int per = ORD_CELLS / 1024;
+    unsigned local = 0;
+    for (int j = 0; j < per; ++j) local += hist[tid * per + j];
+    unsigned incl = local;
+#pragma unroll
+    for (int dlt = 1; dlt < WAVE; dlt <<= 1) {
+        const unsigned o = __shfl_up(incl, dlt, WAVE);
+        if (lane >= dlt) incl += o;
     }
-    for (int i = threadIdx.x; i < n; i += blockDim.x) perm[base + i] = base + (int)(skey[i] & 0xFFFFFFFFu);
+    if (lane == WAVE - 1) wsum[wave] = incl;
+    __syncthreads();
+    unsigned wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += wsum[w];
+    unsigned run = wbase + incl - local;
+    for (int j = 0; j < per; ++j) {
+        const unsigned cnt = hist[tid * per + j];
+        hist[tid * per + j] = run;
+        run += cnt;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ORD_PER_THREAD; ++k) {
+        const int i = tid + k * 1024;
+        if (i < n) perm[base + hist[key[k]] + ticket[k]] = base + i;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -92,7 +146,7 @@ __global__ __launch_bounds__(256) void scatter_sort_kernel(const PlaneSet planes
                                                            const float* __restrict__ rays_d,
                                                            const float* __restrict__ z_vals,     // RENDER ? [R,S] : pts [N,3]
                                                            const int* __restrict__ perm, int R, int S,
-                                                           const float* __restrict__ g_feat, int bundle) {
+                                                           const float* __restrict__ g_feat, int bundle, int dbg_mode) {
     __shared__ unsigned skey[BUNDLE_MAX];          // (cell << 10) | local sample slot, sorted
     __shared__ unsigned sxy[BUNDLE_MAX];           // per slot: x0 | y0 << 12 | (x1 > x0) << 24 | (y1 > y0) << 25
     __shared__ float swx[BUNDLE_MAX], swy[BUNDLE_MAX];   // per slot: bilinear fractions
@@ -161,53 +215,76 @@ __global__ __launch_bounds__(256) void scatter_sort_kernel(const PlaneSet planes
             __syncthreads();
         }
     }
-    // (3) walk: wave w owns sorted entries [w*256, w*256+256)
+    if (dbg_mode == 2) return;      // profiling only (tools/dbg_scatter.py): cost of phases 1+2
+    // (3) walk: wave w owns sorted entries [w*256, w*256+256).  Per 64 entries every lane first fetches ONE entry's
+    // record from LDS (cell, g_feat row, fractions); the walk then reads them with v_readlane (no LDS latency in the
+    // loop) and keeps the g_feat loads of the next 8 entries in flight while it accumulates the current 8.
     const float* __restrict__ gcol = g_feat + d * 64 + lvl * 32 + c;
+    const int DUMMY = 0x3FFFFF;                    // cell of padding entries: never flushed
     int cur_cell = -1;
     unsigned cur_xy = 0;
     float acc0 = 0.f, acc1 = 0.f;
     const int e0 = wave * (BUNDLE_MAX / 4);
+
+    auto flush = [&]() {
+        if (cur_cell >= 0 && cur_cell != DUMMY) {
+            const int x0 = cur_xy & 0xFFF, y0 = (cur_xy >> 12) & 0xFFF;
+            const int dxs = ((cur_xy >> 24) & 1) * psx, dys = ((cur_xy >> 25) & 1) * psy;
+            float* gp = grad + y0 * psy + x0 * psx + hx * dxs + c * psc;
+            if (dbg_mode != 1) {
+                atomicAdd(gp, acc0);
+                atomicAdd(gp + dys, acc1);
+            } else if (acc0 == 1.2345e30f) gp[0] = acc1;      // profiling only: walk without atomics
+        }
+    };
+
 #pragma unroll 1
-    for (int e = e0; e < e0 + BUNDLE_MAX / 4; e += 4) {
-        unsigned key[4];
-        float g[4];
+    for (int blk = 0; blk < BUNDLE_MAX / 4 / WAVE; ++blk) {
+        const unsigned k = skey[e0 + blk * WAVE + lane];
+        const bool valid = k != 0xFFFFFFFFu;
+        const int slot = k & 1023u;
+        const int my_cell = valid ? (int)(k >> 10) : DUMMY;
+        const int my_row = valid ? sgrow[slot] : 0;
+        const unsigned my_xy = valid ? sxy[slot] : 0u;
+        const float my_tx = valid ? swx[slot] : 0.f, my_ty = valid ? swy[slot] : 0.f;
+        if (__builtin_amdgcn_readfirstlane(my_cell) == DUMMY) break;          // sorted: everything from here is padding
+
+        float gbuf[2][8];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            key[t] = skey[e + t];                                         // LDS broadcast reads (wave-uniform)
-            const int slot = key[t] & 1023u;
-            g[t] = (key[t] != 0xFFFFFFFFu) ? gcol[(int64_t)sgrow[slot] * 128] : 0.0f;
+        for (int t = 0; t < 8; ++t) {
+            const int row = __builtin_amdgcn_readlane(my_row, t);
+            gbuf[0][t] = gcol[(int64_t)row * 128];
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (key[t] == 0xFFFFFFFFu) break;                             // wave-uniform: padding from here on
-            const int slot = key[t] & 1023u;
-            const int cell = (int)(key[t] >> 10);
-            if (cell != cur_cell) {                                        // wave-uniform
-                if (cur_cell >= 0) {
-                    const int x0 = cur_xy & 0xFFF, y0 = (cur_xy >> 12) & 0xFFF;
-                    const int dxs = ((cur_xy >> 24) & 1) * psx, dys = ((cur_xy >> 25) & 1) * psy;
-                    float* gp = grad + y0 * psy + x0 * psx + hx * dxs + c * psc;
-                    atomicAdd(gp, acc0);
-                    atomicAdd(gp + dys, acc1);
+        for (int grp = 0; grp < 8; ++grp) {
+            if (grp + 1 < 8) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int row = __builtin_amdgcn_readlane(my_row, (grp + 1) * 8 + t);
+                    gbuf[(grp + 1) & 1][t] = gcol[(int64_t)row * 128];
                 }
-                cur_cell = cell;
-                cur_xy = sxy[slot];
-                acc0 = 0.f;
-                acc1 = 0.f;
             }
-            const float tx = swx[slot], ty = swy[slot];
-            const float wx = hx ? tx : 1.0f - tx;
-            acc0 += g[t] * (wx * (1.0f - ty));
-            acc1 += g[t] * (wx * ty);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int idx = grp * 8 + t;
+                const int cell = __builtin_amdgcn_readlane(my_cell, idx);
+                if (cell != cur_cell) {                                            // wave-uniform
+                    flush();
+                    cur_cell = cell;
+                    cur_xy = (unsigned)__builtin_amdgcn_readlane((int)my_xy, idx);
+                    acc0 = 0.f;
+                    acc1 = 0.f;
+                }
+                const float tx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_tx), idx));
+                const float ty = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_ty), idx));
+                const float wx = hx ? tx : 1.0f - tx;
+                const float g = (cell != DUMMY) ? gbuf[grp & 1][t] : 0.0f;
+                acc0 += g * (wx * (1.0f - ty));
+                acc1 += g * (wx * ty);
+            }
         }
     }
-    if (cur_cell >= 0) {
-        const int x0 = cur_xy & 0xFFF, y0 = (cur_xy >> 12) & 0xFFF;
-        const int dxs = ((cur_xy >> 24) & 1) * psx, dys = ((cur_xy >> 25) & 1) * psy;
-        float* gp = grad + y0 * psy + x0 * psx + hx * dxs + c * psc;
-        atomicAdd(gp, acc0);
-        atomicAdd(gp + dys, acc1);
-    }
+    flush();
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -232,14 +309,12 @@ int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float*
     }
     const int64_t N = render ? R * S : R;
     const int nunits = render ? (int)R : (int)((N + 63) / 64);
-    static const int nosort = env_int("ESLAM_SC_NOSORT", 0);       // A/B switch for profiling only
+    static const int nosort = env_int("ESLAM_SC_NOSORT", 0), dbg_mode = env_int("ESLAM_SC_MODE", 0);       // A/B switch for profiling only
     if (nosort) perm = nullptr;
     if (render && perm) {
         const int chunks = (int)((R + SORT_MAX - 1) / SORT_MAX);
-        int npow = 1;
-        while (npow < (R < SORT_MAX ? (int)R : SORT_MAX)) npow <<= 1;
-        hipLaunchKernelGGL(ray_order_kernel, dim3(chunks), dim3(1024), npow * sizeof(unsigned long long), st, rays_o,
-                           rays_d, (int)R, bnd, perm);
+        hipLaunchKernelGGL(ray_order_kernel, dim3(chunks), dim3(1024), ORD_CELLS * sizeof(unsigned), st, rays_o, rays_d,
+                           (int)R, perm);
         if (int rc = eslam_check_launch("ray_order_kernel")) return rc;
     }
     const int per = render ? S : 64;
@@ -247,10 +322,10 @@ int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float*
     dim3 grid((nunits + bundle - 1) / bundle, NPL), block(256);
     if (render)
         hipLaunchKernelGGL((scatter_sort_kernel<true>), grid, block, 0, st, ps, bnd, rays_o, rays_d, z_or_pts,
-                           (const int*)perm, (int)R, S, g_feat, bundle);
+                           (const int*)perm, (int)R, S, g_feat, bundle, dbg_mode);
     else
         hipLaunchKernelGGL((scatter_sort_kernel<false>), grid, block, 0, st, ps, bnd, rays_o, rays_d, z_or_pts,
-                           (const int*)nullptr, (int)R, 64, g_feat, bundle);
+                           (const int*)nullptr, (int)R, 64, g_feat, bundle, dbg_mode);
     return eslam_check_launch("scatter_sort_kernel");
 }
 
@@ -258,7 +333,7 @@ int eslam_scatter_v2_init() {
     static bool done = false;
     if (done) return 0;
     if (hipFuncSetAttribute((const void*)ray_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            SORT_MAX * (int)sizeof(unsigned long long)) != hipSuccess) {
+                            ORD_CELLS * (int)sizeof(unsigned)) != hipSuccess) {
         eslam_set_error("scatter: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
         return 2;
     }
