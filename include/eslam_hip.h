@@ -104,10 +104,16 @@ int eslam_importance_z(const eslam_plane_t* planes, const eslam_decoders_t* dec,
  * src/common.py:204-218:  pts = o + d z -> normalise -> tri-plane bilinear gather (border, align_corners) ->
  * SDF / colour MLPs -> sdf2alpha -> transmittance scan -> composite.
  * Outputs: depth [R], rgb [R,3], sdf [R,S].  For a later backward pass also raw_rgb [R,S,3] (sigmoid outputs)
- * and feat [R*S,128] (geometry 64 || colour 64 features per sample); both may be NULL for inference.        */
+ * and feat [R*S,128] (geometry 64 || colour 64 features per sample); both may be NULL for inference.
+ * ray_order [R] (optional, out): when given, the rays are first ordered by direction (counting sort) and the
+ * kernel walks them in that order with an XCD-contiguous block mapping, so rays through neighbouring pixels run
+ * on neighbouring CUs and share L2 lines; outputs stay in the caller's ray order.  Hand the same buffer to
+ * eslam_render_bwd, which needs the order for its scatter.  NULL = rays are processed as given (e.g. render_img,
+ * whose rays are already in image order).                                                                  */
 int eslam_render_fwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
                      const float* rays_o, const float* rays_d, const float* z_vals, int R, int S, float* depth,
-                     float* rgb, float* sdf, float* raw_rgb, float* feat, eslam_stream_t stream);
+                     float* rgb, float* sdf, float* raw_rgb, float* feat, int32_t* ray_order,
+                     eslam_stream_t stream);
 
 /* Bytes of scratch eslam_render_bwd / eslam_decode_bwd need for n_points = R*S points.               */
 int64_t eslam_bwd_workspace_bytes(int64_t n_points);
@@ -117,12 +123,13 @@ int64_t eslam_bwd_workspace_bytes(int64_t n_points);
  * Accumulates into planes[i].grad (where non-NULL), OVERWRITES g_dec [ESLAM_N_DEC_PARAMS] (order of
  * eslam_decoders_t: w1,b1,w2,b2,w3,b3,cw1,...,cb3) and g_beta [1], and when g_rays_o / g_rays_d are
  * non-NULL overwrites them ([R,3] each) with the gradient through pts = o + d z.  z_vals carries no gradient
- * (Renderer.py builds it under no_grad / from gt_depth).  workspace: eslam_bwd_workspace_bytes(R*S) bytes. */
+ * (Renderer.py builds it under no_grad / from gt_depth).  ray_order: the buffer eslam_render_fwd filled, or NULL
+ * (then the order is computed here).  workspace: eslam_bwd_workspace_bytes(R*S) bytes.                      */
 int eslam_render_bwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
                      const float* rays_o, const float* rays_d, const float* z_vals, int R, int S,
                      const float* sdf, const float* raw_rgb, const float* feat, const float* g_depth,
                      const float* g_rgb, const float* g_sdf, float* g_dec, float* g_beta, float* g_rays_o,
-                     float* g_rays_d, void* workspace, eslam_stream_t stream);
+                     float* g_rays_d, const int32_t* ray_order, void* workspace, eslam_stream_t stream);
 
 /* Decoder-only query.  Replaces src/networks/decoders.py:127-146 (Decoders.forward), the entry used by
  * src/utils/Mesher.py:151 on up to 500k points.  pts [N,3] world coordinates -> raw [N,4] = (r,g,b,sdf).

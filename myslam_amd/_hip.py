@@ -45,10 +45,10 @@ SIGNATURES = {
     "eslam_aabb_exit": (_i, [_vp, _vp, _i, _BP, _vp, _vp]),
     "eslam_sample_z": (_i, [_vp, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp]),
     "eslam_importance_z": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "eslam_render_fwd": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "eslam_render_fwd": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "eslam_bwd_workspace_bytes": (_i64, [_i64]),
     "eslam_render_bwd": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                              _vp, _vp]),
+                              _vp, _vp, _vp]),
     "eslam_decode_fwd": (_i, [_PP, _DP, _BP, _vp, _i64, _i, _vp, _vp, _vp]),
     "eslam_decode_bwd": (_i, [_PP, _DP, _BP, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "eslam_mapping_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _BP, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -605,9 +605,9 @@ static Bound make_bound(const float* b6) {
 #define MLP_BWD_MAX_WG 512
 
 int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float* rays_o, const float* rays_d,
-                     const float* z_or_pts, int64_t R, int S, bool render, const float* g_feat, int* perm,
+                     const float* z_or_pts, int64_t R, int S, bool render, const float* g_feat, const int* perm,
                      hipStream_t st);
-int eslam_scatter_v2_init();
+int eslam_ray_order(const float* rays_o, const float* rays_d, int R, int* perm, hipStream_t st);
 
 static int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
 
@@ -625,7 +625,7 @@ extern "C" int64_t eslam_bwd_workspace_bytes(int64_t n_points) {
 
 static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, const Bound& bnd, const float* rays_o,
                       const float* rays_d, const float* z_or_pts, int64_t R, int S, bool render, const float* feat,
-                      float* g_o, float* g_feat, float* slabs, int* perm, float* g_dec, float* g_out_a, float* g_out_b,
+                      float* g_o, float* g_feat, float* slabs, const int* perm, float* g_dec, float* g_out_a, float* g_out_b,
                       const float* beta_parts, int n_beta_parts, float* g_beta, hipStream_t st) {
     const int64_t N = render ? R * S : R;
     PlaneSet ps;
@@ -657,7 +657,6 @@ static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, 
     }
     static const bool use_v1 = getenv("ESLAM_SCATTER_V1") != nullptr;     // A/B switch for profiling only
     if (any_grad && !use_v1) {
-        if (int rc = eslam_scatter_v2_init()) return rc;
         eslam_prof_begin(PROF_SCATTER, st);
         if (int rc = eslam_scatter_v2(planes, bnd, rays_o, rays_d, z_or_pts, R, S, render, g_feat, perm, st)) return rc;
         eslam_prof_end(PROF_SCATTER, st);
@@ -695,7 +694,7 @@ extern "C" int eslam_render_bwd(const eslam_plane_t* planes, const eslam_decoder
                                 const float* rays_o, const float* rays_d, const float* z_vals, int R, int S,
                                 const float* sdf, const float* raw_rgb, const float* feat, const float* g_depth,
                                 const float* g_rgb, const float* g_sdf, float* g_dec, float* g_beta, float* g_rays_o,
-                                float* g_rays_d, void* workspace, eslam_stream_t stream) {
+                                float* g_rays_d, const int32_t* ray_order, void* workspace, eslam_stream_t stream) {
     if (R <= 0) return 0;
     if (S <= 0 || S > ESLAM_MAX_SAMPLES) {
         eslam_set_error("eslam_render_bwd: S=%d outside [1,%d]", S, ESLAM_MAX_SAMPLES);
@@ -721,7 +720,12 @@ extern "C" int eslam_render_bwd(const eslam_plane_t* planes, const eslam_decoder
     float* g_o = (float*)ws;
     float* g_feat = (float*)(ws + align256(N * 16));
     float* slabs = (float*)(ws + align256(N * 16) + align256(N * 512));
-    int* perm = (int*)(ws + align256(N * 16) + align256(N * 512) + align256(slab_region_bytes(N)));
+    const int* perm = ray_order;
+    if (!perm) {      // the forward pass did not leave an order: compute it here
+        int* own = (int*)(ws + align256(N * 16) + align256(N * 512) + align256(slab_region_bytes(N)));
+        if (int rc = eslam_ray_order(rays_o, rays_d, R, own, st)) return rc;
+        perm = own;
+    }
     const Bound bnd = make_bound(bound6_host);
 
     // g_beta partials: one float per composite_bwd workgroup, stored behind the decoder-gradient slabs

@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256, 4) void render_fwd_kernel(const PlaneSet plane
                                                          const float* __restrict__ z_vals, int R, int S,
                                                          float* __restrict__ depth_out, float* __restrict__ rgb_out,
                                                          float* __restrict__ sdf_out, float* __restrict__ raw_rgb_out,
-                                                         float* __restrict__ feat_out) {
+                                                         float* __restrict__ feat_out, const int* __restrict__ perm) {
     __shared__ __attribute__((aligned(16))) float wlds[2 * DEC_LDS];
     stage_decoder_weights(wlds, dec, threadIdx.x, blockDim.x);
     __syncthreads();
@@ -23,8 +23,15 @@ __global__ __launch_bounds__(256, 4) void render_fwd_kernel(const PlaneSet plane
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const int ray = blockIdx.x * 4 + wave;
-    if (ray >= R) return;
+    // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one, MI355X_MICROARCH.md).  Give every
+    // XCD a contiguous run of the ray order, so that rays through neighbouring pixels - which read the same texels -
+    // are resident on CUs behind the same L2.  Placement only affects speed: the grid has 8*cpx blocks, every logical
+    // block is taken exactly once, surplus blocks exit.
+    const int cpx = gridDim.x >> 3;
+    const int lblock = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+    const int slot = lblock * 4 + wave;
+    if (slot >= R) return;
+    const int ray = perm ? perm[slot] : slot;
 
     const float ox = rays_o[ray * 3 + 0], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
     const float dx = rays_d[ray * 3 + 0], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
@@ -166,6 +173,7 @@ __global__ __launch_bounds__(256, 4) void decode_fwd_kernel(const PlaneSet plane
 // ---------------------------------------------------------------------------------------------------------
 bool eslam_planes_channels_last(const eslam_plane_t* planes, int first, int count);
 int eslam_validate_planes(const eslam_plane_t* planes, int first, int count);
+int eslam_ray_order(const float* rays_o, const float* rays_d, int R, int* perm, hipStream_t st);
 
 static Bound make_bound(const float* b6) {
     Bound b;
@@ -179,7 +187,7 @@ static Bound make_bound(const float* b6) {
 
 extern "C" int eslam_render_fwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
                                 const float* rays_o, const float* rays_d, const float* z_vals, int R, int S,
-                                float* depth, float* rgb, float* sdf, float* raw_rgb, float* feat,
+                                float* depth, float* rgb, float* sdf, float* raw_rgb, float* feat, int32_t* ray_order,
                                 eslam_stream_t stream) {
     if (R <= 0) return 0;
     if (S <= 0 || S > ESLAM_MAX_SAMPLES) {
@@ -200,11 +208,14 @@ extern "C" int eslam_render_fwd(const eslam_plane_t* planes, const eslam_decoder
     const Bound bnd = make_bound(bound6_host);
     const bool cl = eslam_planes_channels_last(planes, 0, NPL);
     const bool save = feat != nullptr;
-    dim3 grid((R + 3) / 4), block(256);
+    const int nblocks = (R + 3) / 4;
+    dim3 grid(((nblocks + 7) / 8) * 8), block(256);
     hipStream_t st = (hipStream_t)stream;
+    if (ray_order)
+        if (int rc = eslam_ray_order(rays_o, rays_d, R, ray_order, st)) return rc;
 #define LAUNCH(CLv, SV)                                                                                             \
     hipLaunchKernelGGL((render_fwd_kernel<CLv, SV>), grid, block, 0, st, ps, *dec, bnd, rays_o, rays_d, z_vals, R, \
-                       S, depth, rgb, sdf, raw_rgb, feat)
+                       S, depth, rgb, sdf, raw_rgb, feat, (const int*)ray_order)
     eslam_prof_begin(PROF_RENDER_FWD, st);
     if (cl && save) LAUNCH(true, true);
     else if (cl) LAUNCH(true, false);

@@ -200,25 +200,45 @@ __global__ __launch_bounds__(256) void scatter_sort_kernel(const PlaneSet planes
         skey[slot] = key;
     }
     __syncthreads();
-    // (2) bitonic sort of the keys (invalid slots carry the maximum key and end up last)
-    for (int k = 2; k <= BUNDLE_MAX; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
+    // (2) bitonic sort of the keys (invalid slots carry the maximum key and end up last).  Wave w owns elements
+    // [256w, 256w+256): every compare-exchange distance j < 256 stays inside one wave's chunk and needs no workgroup
+    // barrier (DS operations of a wave execute in order); only the 3 stages with j >= 256 synchronise the workgroup.
+    {
+        const int wbase = wave * (BUNDLE_MAX / 4);
+        for (int k = 2; k <= BUNDLE_MAX; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                if (j >= BUNDLE_MAX / 4) {
+                    __syncthreads();
 #pragma unroll
-            for (int t = 0; t < BUNDLE_MAX / 512; ++t) {
-                const int p = threadIdx.x + t * 256;                      // pair index
-                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));      // lower element of the pair
-                const int l = i | j;
-                const unsigned a = skey[i], b = skey[l];
-                const bool up = (i & k) == 0;
-                if ((a > b) == up) { skey[i] = b; skey[l] = a; }
+                    for (int t = 0; t < BUNDLE_MAX / 512; ++t) {
+                        const int p = threadIdx.x + t * 256;                      // pair index
+                        const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));      // lower element of the pair
+                        const int l = i | j;
+                        const unsigned a = skey[i], b2 = skey[l];
+                        if ((a > b2) == ((i & k) == 0)) { skey[i] = b2; skey[l] = a; }
+                    }
+                    __syncthreads();
+                } else {
+#pragma unroll
+                    for (int t = 0; t < BUNDLE_MAX / 512; ++t) {
+                        const int p = lane + t * WAVE;                            // pair index inside the wave's chunk
+                        const int i = wbase + (((p & ~(j - 1)) << 1) | (p & (j - 1)));
+                        const int l = i | j;
+                        const unsigned a = skey[i], b2 = skey[l];
+                        if ((a > b2) == ((i & k) == 0)) { skey[i] = b2; skey[l] = a; }
+                    }
+                    WAVE_SYNC();
+                }
             }
-            __syncthreads();
         }
     }
     if (dbg_mode == 2) return;      // profiling only (tools/dbg_scatter.py): cost of phases 1+2
-    // (3) walk: wave w owns sorted entries [w*256, w*256+256).  Per 64 entries every lane first fetches ONE entry's
-    // record from LDS (cell, g_feat row, fractions); the walk then reads them with v_readlane (no LDS latency in the
-    // loop) and keeps the g_feat loads of the next 8 entries in flight while it accumulates the current 8.
+
+    // (3) walk: wave w owns sorted entries [256w, 256w+256), 64 at a time.  Every lane fetches ONE entry's record from
+    // LDS (cell, g_feat row, fractions); the walk reads records with v_readlane.  The g_feat values of 32 entries are
+    // loaded ahead of the walk of the previous 32: a wave's loads, stores and atomics retire in order on one vmcnt
+    // counter, so a load issued BEHIND an atomic would wait for it (~3000 cycles under load); issued ahead of them, the
+    // loads only ever wait for other loads.
     const float* __restrict__ gcol = g_feat + d * 64 + lvl * 32 + c;
     const int DUMMY = 0x3FFFFF;                    // cell of padding entries: never flushed
     int cur_cell = -1;
@@ -238,52 +258,71 @@ __global__ __launch_bounds__(256) void scatter_sort_kernel(const PlaneSet planes
         }
     };
 
-#pragma unroll 1
-    for (int blk = 0; blk < BUNDLE_MAX / 4 / WAVE; ++blk) {
+    struct Rec { int cell, row; unsigned xy; float tx, ty; };
+    auto fetch = [&](int blk) {
+        Rec r;
         const unsigned k = skey[e0 + blk * WAVE + lane];
         const bool valid = k != 0xFFFFFFFFu;
         const int slot = k & 1023u;
-        const int my_cell = valid ? (int)(k >> 10) : DUMMY;
-        const int my_row = valid ? sgrow[slot] : 0;
-        const unsigned my_xy = valid ? sxy[slot] : 0u;
-        const float my_tx = valid ? swx[slot] : 0.f, my_ty = valid ? swy[slot] : 0.f;
-        if (__builtin_amdgcn_readfirstlane(my_cell) == DUMMY) break;          // sorted: everything from here is padding
-
-        float gbuf[2][8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int row = __builtin_amdgcn_readlane(my_row, t);
-            gbuf[0][t] = gcol[(int64_t)row * 128];
-        }
-#pragma unroll
-        for (int grp = 0; grp < 8; ++grp) {
-            if (grp + 1 < 8) {
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int row = __builtin_amdgcn_readlane(my_row, (grp + 1) * 8 + t);
-                    gbuf[(grp + 1) & 1][t] = gcol[(int64_t)row * 128];
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int idx = grp * 8 + t;
-                const int cell = __builtin_amdgcn_readlane(my_cell, idx);
-                if (cell != cur_cell) {                                            // wave-uniform
-                    flush();
-                    cur_cell = cell;
-                    cur_xy = (unsigned)__builtin_amdgcn_readlane((int)my_xy, idx);
-                    acc0 = 0.f;
-                    acc1 = 0.f;
-                }
-                const float tx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_tx), idx));
-                const float ty = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_ty), idx));
-                const float wx = hx ? tx : 1.0f - tx;
-                const float g = (cell != DUMMY) ? gbuf[grp & 1][t] : 0.0f;
-                acc0 += g * (wx * (1.0f - ty));
-                acc1 += g * (wx * ty);
-            }
-        }
+        r.cell = valid ? (int)(k >> 10) : DUMMY;
+        r.row = valid ? sgrow[slot] : 0;
+        r.xy = valid ? sxy[slot] : 0u;
+        r.tx = valid ? swx[slot] : 0.f;
+        r.ty = valid ? swy[slot] : 0.f;
+        return r;
+    };
+#ifndef WALK_N
+#define WALK_N 8                   // entries per load-ahead group (2 groups in flight: 2*WALK_N VGPRs)
+#endif
+#define LOAD_HALF(buf, rec, half)                                                             \
+    _Pragma("unroll") for (int t = 0; t < WALK_N; ++t) {                                      \
+        const int row = __builtin_amdgcn_readlane((rec).row, (half) * WALK_N + t);            \
+        buf[t] = gcol[(int64_t)row * 128];                                                    \
     }
+#define WALK_HALF(buf, rec, half)                                                             \
+    _Pragma("unroll") for (int t = 0; t < WALK_N; ++t) {                                      \
+        const int idx = (half) * WALK_N + t;                                                  \
+        const int cell = __builtin_amdgcn_readlane((rec).cell, idx);                          \
+        if (cell != cur_cell) {                                                               \
+            flush();                                                                          \
+            cur_cell = cell;                                                                  \
+            cur_xy = (unsigned)__builtin_amdgcn_readlane((int)(rec).xy, idx);                 \
+            acc0 = 0.f;                                                                       \
+            acc1 = 0.f;                                                                       \
+        }                                                                                     \
+        const float tx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (rec).tx), idx)); \
+        const float ty = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (rec).ty), idx)); \
+        const float wx = hx ? tx : 1.0f - tx;                                                 \
+        const float g = (cell != DUMMY) ? buf[t] : 0.0f;                                      \
+        acc0 += g * (wx * (1.0f - ty));                                                       \
+        acc1 += g * (wx * ty);                                                                \
+    }
+
+    const int nblk = BUNDLE_MAX / 4 / WAVE;
+    const int ngrp = WAVE / WALK_N;                 // groups per 64-entry record block (even)
+    float ga[WALK_N], gb[WALK_N];
+    Rec rec = fetch(0);
+    LOAD_HALF(ga, rec, 0)
+#pragma unroll 1
+    for (int blk = 0; blk < nblk; ++blk) {
+        if (__builtin_amdgcn_readfirstlane(rec.cell) == DUMMY) break;          // sorted: everything from here is padding
+        Rec nxt = rec;
+        if (blk + 1 < nblk) nxt = fetch(blk + 1);
+#pragma unroll
+        for (int g2 = 0; g2 < ngrp; g2 += 2) {
+            LOAD_HALF(gb, rec, g2 + 1)
+            WALK_HALF(ga, rec, g2)
+            if (g2 + 2 < ngrp) {
+                LOAD_HALF(ga, rec, g2 + 2)
+            } else if (blk + 1 < nblk) {
+                LOAD_HALF(ga, nxt, 0)
+            }
+            WALK_HALF(gb, rec, g2 + 1)
+        }
+        rec = nxt;
+    }
+#undef LOAD_HALF
+#undef WALK_HALF
     flush();
 }
 
@@ -295,8 +334,20 @@ static int env_int(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
+int eslam_scatter_v2_init();
+
+// perm [R] <- rays ordered by direction; chunks of SORT_MAX rays are ordered independently
+int eslam_ray_order(const float* rays_o, const float* rays_d, int R, int* perm, hipStream_t st) {
+    if (int rc = eslam_scatter_v2_init()) return rc;
+    const int chunks = (R + SORT_MAX - 1) / SORT_MAX;
+    hipLaunchKernelGGL(ray_order_kernel, dim3(chunks), dim3(1024), ORD_CELLS * sizeof(unsigned), st, rays_o, rays_d, R,
+                       perm);
+    return eslam_check_launch("ray_order_kernel");
+}
+
+// perm: ray order to bundle by (render mode), or NULL for the given order
 int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float* rays_o, const float* rays_d,
-                     const float* z_or_pts, int64_t R, int S, bool render, const float* g_feat, int* perm,
+                     const float* z_or_pts, int64_t R, int S, bool render, const float* g_feat, const int* perm,
                      hipStream_t st) {
     PlaneSet ps;
     for (int i = 0; i < NPL; ++i) {
@@ -311,18 +362,12 @@ int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float*
     const int nunits = render ? (int)R : (int)((N + 63) / 64);
     static const int nosort = env_int("ESLAM_SC_NOSORT", 0), dbg_mode = env_int("ESLAM_SC_MODE", 0);       // A/B switch for profiling only
     if (nosort) perm = nullptr;
-    if (render && perm) {
-        const int chunks = (int)((R + SORT_MAX - 1) / SORT_MAX);
-        hipLaunchKernelGGL(ray_order_kernel, dim3(chunks), dim3(1024), ORD_CELLS * sizeof(unsigned), st, rays_o, rays_d,
-                           (int)R, perm);
-        if (int rc = eslam_check_launch("ray_order_kernel")) return rc;
-    }
     const int per = render ? S : 64;
     const int bundle = BUNDLE_MAX / per;          // S <= ESLAM_MAX_SAMPLES = 256 -> at least 4 rays
     dim3 grid((nunits + bundle - 1) / bundle, NPL), block(256);
     if (render)
         hipLaunchKernelGGL((scatter_sort_kernel<true>), grid, block, 0, st, ps, bnd, rays_o, rays_d, z_or_pts,
-                           (const int*)perm, (int)R, S, g_feat, bundle, dbg_mode);
+                           perm, (int)R, S, g_feat, bundle, dbg_mode);
     else
         hipLaunchKernelGGL((scatter_sort_kernel<false>), grid, block, 0, st, ps, bnd, rays_o, rays_d, z_or_pts,
                            (const int*)nullptr, (int)R, 64, g_feat, bundle, dbg_mode);

@@ -103,5 +103,34 @@ class Workload:
         return loss
 
 
+class GraphedStep:
+    """One mapping iteration captured into a hipGraph (torch.cuda.CUDAGraph) and replayed.
+
+    A step is ~14 kernel launches of 5-250 us each; issued eagerly from Python they cost more host time than the GPU
+    needs to run them, so the iteration is captured once (our C-ABI calls only enqueue on the current stream: no
+    allocation, no sync) and replayed.  Every replay does the full work - new random jitter (the Philox offset of
+    torch's generator advances per replay), forward, loss, backward - into static gradient buffers (p.grad)."""
+
+    def __init__(self, step_fn, params, warmup=3):
+        self.params = list(params)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                step_fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for p in self.params:
+            p.grad = None
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = step_fn()
+        torch.cuda.synchronize()
+
+    def __call__(self):
+        self.graph.replay()
+        return self.loss
+
+
 def make_workload(scene_name, R, n_strat, n_imp, device, **kw):
     return Workload(scene_name, R, n_strat, n_imp, device, **kw)

@@ -125,21 +125,22 @@ class RenderFn(torch.autograd.Function):
         sdf = torch.empty(R, S, device=dev)
         raw_rgb = torch.empty(R, S, 3, device=dev) if needs else None
         feat = torch.empty(R * S, 128, device=dev) if needs else None
+        order = torch.empty(R, dtype=torch.int32, device=dev) if needs else None
         with torch.cuda.device(dev):
             _hip.check(lib.eslam_render_fwd(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(rays_o),
                                             _hip.ptr(rays_d), _hip.ptr(z_vals), R, S, _hip.ptr(depth), _hip.ptr(rgb),
-                                            _hip.ptr(sdf), _hip.ptr(raw_rgb), _hip.ptr(feat),
+                                            _hip.ptr(sdf), _hip.ptr(raw_rgb), _hip.ptr(feat), _hip.ptr(order),
                                             _hip.stream_handle(dev)), "eslam_render_fwd")
         if needs:
             ctx.bound6 = bound6
-            ctx.save_for_backward(rays_o, rays_d, z_vals, sdf, raw_rgb, feat, beta, *planes, *params)
+            ctx.save_for_backward(rays_o, rays_d, z_vals, sdf, raw_rgb, feat, order, beta, *planes, *params)
         return depth, rgb, sdf
 
     @staticmethod
     def backward(ctx, g_depth, g_rgb, g_sdf):
         saved = ctx.saved_tensors
-        rays_o, rays_d, z_vals, sdf, raw_rgb, feat, beta = saved[:7]
-        planes, params = saved[7:19], saved[19:31]
+        rays_o, rays_d, z_vals, sdf, raw_rgb, feat, order, beta = saved[:8]
+        planes, params = saved[8:20], saved[20:32]
         R, S = z_vals.shape
         dev = rays_o.device
         lib = _hip.lib()
@@ -173,7 +174,8 @@ class RenderFn(torch.autograd.Function):
                                             _hip.ptr(rays_d), _hip.ptr(z_vals), R, S, _hip.ptr(sdf), _hip.ptr(raw_rgb),
                                             _hip.ptr(feat), _hip.ptr(g_depth), _hip.ptr(g_rgb), _hip.ptr(g_sdf),
                                             _hip.ptr(g_dec), _hip.ptr(g_beta), _hip.ptr(g_ro), _hip.ptr(g_rd),
-                                            _hip.ptr(ws), _hip.stream_handle(dev)), "eslam_render_bwd")
+                                            _hip.ptr(order), _hip.ptr(ws), _hip.stream_handle(dev)),
+                       "eslam_render_bwd")
         if sink is not None:
             # the data-parallel caller owns .grad assignment (FlatGrads.assign): hand autograd nothing to accumulate
             return (g_ro if need[0] else None, g_rd if need[1] else None) + (None,) * 27
