@@ -201,19 +201,26 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const eslam_decoders_t dec
         for (int o = 0; o < 3; ++o) gb3[o] += go[o];
         *(float4_t*)(gt + lane * 4) = (float4_t){go[0], go[1], go[2], go[3]};
 
-#pragma unroll 1
-        for (int b = 0; b < nblk; ++b) {
-            // block role: features of point 16b + r (gather layout, 8 channels per level)
+        // block role: features of point 16b + r (gather layout, 8 channels per level).  The rows of block b+1 are
+        // requested before block b is computed: at 2 waves per SIMD nothing else hides the ~2k-cycle load latency.
+        auto load_block = [&](int b, float4_t v[4]) {
             const int64_t pt = min(p0 + 16 * b + r, N - 1);
             const float* fp = feat + pt * 128 + d * 64 + 8 * q;
+            v[0] = *(const float4_t*)(fp);
+            v[1] = *(const float4_t*)(fp + 4);
+            v[2] = *(const float4_t*)(fp + 32);
+            v[3] = *(const float4_t*)(fp + 36);
+        };
+        float4_t fnext[4];
+        load_block(0, fnext);
+#pragma unroll 1
+        for (int b = 0; b < nblk; ++b) {
             float ft[16];
 #pragma unroll
-            for (int lvl = 0; lvl < 2; ++lvl) {
-                const float4_t a = *(const float4_t*)(fp + lvl * 32);
-                const float4_t c = *(const float4_t*)(fp + lvl * 32 + 4);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { ft[lvl * 8 + i] = a[i]; ft[lvl * 8 + 4 + i] = c[i]; }
+            for (int i = 0; i < 4; ++i) {
+                ft[i] = fnext[0][i]; ft[4 + i] = fnext[1][i]; ft[8 + i] = fnext[2][i]; ft[12 + i] = fnext[3][i];
             }
+            if (b + 1 < nblk) load_block(b + 1, fnext);
             float4_t h1, h2;
             mlp_hidden(f, ft, h1, h2);
 
@@ -602,7 +609,7 @@ static Bound make_bound(const float* b6) {
     return b;
 }
 
-#define MLP_BWD_MAX_WG 512
+#define MLP_BWD_MAX_WG 256
 
 int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float* rays_o, const float* rays_d,
                      const float* z_or_pts, int64_t R, int S, bool render, const float* g_feat, const int* perm,

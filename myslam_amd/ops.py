@@ -339,9 +339,12 @@ def sample_z(rays_o, rays_d, gt_depth, all_planes, decoders, bound6, truncation,
     S = n_strat + n_imp
     lib = _hip.lib()
     if rand is None:
-        t_rand = torch.rand(R, S, device=dev) if perturb else None
-        t_uni = torch.rand(R, n_strat, device=dev) if perturb else None
-        u = torch.rand(R, n_imp, device=dev)
+        # one draw, three row-major blocks (the reference draws them in three calls, Renderer.py:59, common.py:59)
+        n1, n2 = (R * S, R * n_strat) if perturb else (0, 0)
+        pool = torch.rand(n1 + n2 + R * n_imp, device=dev)
+        t_rand = pool[:n1].view(R, S) if perturb else None
+        t_uni = pool[n1:n1 + n2].view(R, n_strat) if perturb else None
+        u = pool[n1 + n2:].view(R, n_imp)
     else:
         t_rand, t_uni, u = (None if t is None else _c(t) for t in rand)
     z = torch.empty(R, S, device=dev)
@@ -392,5 +395,5 @@ class MappingLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        g_depth, g_rgb, g_sdf = ctx.saved_tensors
-        return g_depth * g, g_rgb * g, g_sdf * g, None, None, None, None, None, None
+        g_depth, g_rgb, g_sdf = torch._foreach_mul(list(ctx.saved_tensors), g)      # one launch instead of three
+        return g_depth, g_rgb, g_sdf, None, None, None, None, None, None

@@ -87,8 +87,8 @@ class ShardedLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        g_depth, g_rgb, g_sdf = ctx.saved_tensors
-        return g_depth * g, g_rgb * g, g_sdf * g, None, None, None, None, None, None
+        g_depth, g_rgb, g_sdf = torch._foreach_mul(list(ctx.saved_tensors), g)
+        return g_depth, g_rgb, g_sdf, None, None, None, None, None, None
 
 
 class ShardedMapper:
