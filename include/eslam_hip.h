@@ -105,15 +105,19 @@ int eslam_importance_z(const eslam_plane_t* planes, const eslam_decoders_t* dec,
  * SDF / colour MLPs -> sdf2alpha -> transmittance scan -> composite.
  * Outputs: depth [R], rgb [R,3], sdf [R,S].  For a later backward pass also raw_rgb [R,S,3] (sigmoid outputs)
  * and feat [R*S,128] (geometry 64 || colour 64 features per sample); both may be NULL for inference.
- * ray_order [R] (optional, out): when given, the rays are first ordered by direction (counting sort) and the
- * kernel walks them in that order with an XCD-contiguous block mapping, so rays through neighbouring pixels run
- * on neighbouring CUs and share L2 lines; outputs stay in the caller's ray order.  Hand the same buffer to
- * eslam_render_bwd, which needs the order for its scatter.  NULL = rays are processed as given (e.g. render_img,
- * whose rays are already in image order).                                                                  */
+ * ray_order [R] (optional, from eslam_ray_order): the kernel walks the rays in that order with an XCD-contiguous
+ * block mapping, so rays through neighbouring pixels run on neighbouring CUs and share L2 lines; outputs stay in the
+ * caller's ray order.  Hand the same buffer to eslam_render_bwd, which needs the order for its scatter.
+ * NULL = rays are processed as given (e.g. render_img, whose rays are already in image order).              */
 int eslam_render_fwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
                      const float* rays_o, const float* rays_d, const float* z_vals, int R, int S, float* depth,
-                     float* rgb, float* sdf, float* raw_rgb, float* feat, int32_t* ray_order,
+                     float* rgb, float* sdf, float* raw_rgb, float* feat, const int32_t* ray_order,
                      eslam_stream_t stream);
+
+/* Ray order for eslam_render_fwd / eslam_render_bwd: perm [R] <- ray ids sorted by a 15-bit Morton key of the point one
+ * metre along each ray (single-pass counting sort, chunks of 8192 rays).  Depends only on the rays, so a caller can
+ * run it on a side stream next to the samplers.                                                              */
+int eslam_ray_order(const float* rays_o, const float* rays_d, int R, int32_t* perm, eslam_stream_t stream);
 
 /* Bytes of scratch eslam_render_bwd / eslam_decode_bwd need for n_points = R*S points.               */
 int64_t eslam_bwd_workspace_bytes(int64_t n_points);

@@ -112,11 +112,71 @@ __device__ __forceinline__ void mlp_out_accum(const DecFrag& f, const float4_t& 
 // table with it keeps the per-plane scalar loads and the values derived from them INSIDE the caller's loop.
 // Without it LICM hoists ~100 loop-invariant scalars of the 12 planes out of the point-block loop, which
 // overflows the SGPR file and ends in VGPR spills to scratch.
+//
+// The six planes of a decoder are gathered through a software pipeline: the 8 x 16-B loads of the next
+// GATHER_PIPELINE planes are issued before the FMAs of plane p (which then wait with vmcnt(8*GATHER_PIPELINE)).  A wave is a chain of 48 dependent
+// load -> FMA steps per ray; with one plane in flight each step exposed the full L2 / Infinity-Cache latency.
+// sched_barrier keeps the compiler from hoisting further ahead (all 48 loads of a block need > 256 VGPRs).
+#ifndef GATHER_PIPELINE
+#define GATHER_PIPELINE 1
+#endif
+
+struct PlaneTaps {              // the 4 corners x 8 channels of one lane and their bilinear weights
+    float4_t a00, b00, a01, b01, a10, b10, a11, b11;
+    float w00, w01, w10, w11;
+};
+
+__device__ __forceinline__ void issue_taps(const eslam_plane_t& P, float u, float v, int q, PlaneTaps& t) {
+    const AxisCoord ax = axis_coord(u, P.w);
+    const AxisCoord ay = axis_coord(v, P.h);
+    t.w00 = (1.0f - ax.t) * (1.0f - ay.t);
+    t.w01 = ax.t * (1.0f - ay.t);
+    t.w10 = (1.0f - ax.t) * ay.t;
+    t.w11 = ax.t * ay.t;
+    const unsigned sy = (unsigned)P.stride_y, sx = (unsigned)P.stride_x;
+    const unsigned r0 = ay.i0 * sy, r1 = ay.i1 * sy;
+    const unsigned c0 = ax.i0 * sx, c1 = ax.i1 * sx;
+    const float* __restrict__ data = P.data;
+    const unsigned q8 = 8u * q;
+    const unsigned o00 = r0 + c0 + q8, o01 = r0 + c1 + q8, o10 = r1 + c0 + q8, o11 = r1 + c1 + q8;
+    t.a00 = *(const float4_t*)(data + o00); t.b00 = *(const float4_t*)(data + o00 + 4u);
+    t.a01 = *(const float4_t*)(data + o01); t.b01 = *(const float4_t*)(data + o01 + 4u);
+    t.a10 = *(const float4_t*)(data + o10); t.b10 = *(const float4_t*)(data + o10 + 4u);
+    t.a11 = *(const float4_t*)(data + o11); t.b11 = *(const float4_t*)(data + o11 + 4u);
+}
+
+__device__ __forceinline__ void accumulate_taps(const PlaneTaps& t, float acc[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        acc[i] += t.a00[i] * t.w00 + t.a01[i] * t.w01 + t.a10[i] * t.w10 + t.a11[i] * t.w11;
+        acc[4 + i] += t.b00[i] * t.w00 + t.b01[i] * t.w01 + t.b10[i] * t.w10 + t.b11[i] * t.w11;
+    }
+}
+
 template <bool CL>
 __device__ __forceinline__ void gather_features(const PlaneSet& planes, int d, float x, float y, float z, int q,
                                                 float feat[16], int opaque0) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) feat[i] = 0.0f;
+    if (CL && GATHER_PIPELINE) {
+        // GATHER_PIPELINE = number of planes whose loads are in flight (ring of tap sets, all indices compile-time)
+        constexpr int D = GATHER_PIPELINE + 1;
+        PlaneTaps taps[D];
+#pragma unroll
+        for (int k = 0; k < D - 1 && k < 6; ++k)
+            issue_taps(planes.p[2 * (3 * d + (k % 3)) + (k / 3) + opaque0], ORIENT_U(k % 3, x, y, z),
+                       ORIENT_V(k % 3, x, y, z), q, taps[k % D]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int kn = k + D - 1;
+            if (kn < 6)
+                issue_taps(planes.p[2 * (3 * d + (kn % 3)) + (kn / 3) + opaque0], ORIENT_U(kn % 3, x, y, z),
+                           ORIENT_V(kn % 3, x, y, z), q, taps[kn % D]);
+            accumulate_taps(taps[k % D], feat + 8 * (k / 3));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
 #pragma unroll
     for (int lvl = 0; lvl < 2; ++lvl) {
 #pragma unroll

@@ -614,7 +614,7 @@ static Bound make_bound(const float* b6) {
 int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float* rays_o, const float* rays_d,
                      const float* z_or_pts, int64_t R, int S, bool render, const float* g_feat, const int* perm,
                      hipStream_t st);
-int eslam_ray_order(const float* rays_o, const float* rays_d, int R, int* perm, hipStream_t st);
+
 
 static int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
 

@@ -9,7 +9,11 @@
 // render: replaces reference src/utils/Renderer.py:136-147 (+ decoders.py:64-146, common.py:204-218)
 // ---------------------------------------------------------------------------------------------------------
 template <bool CL, bool SAVE>
-__global__ __launch_bounds__(256, 4) void render_fwd_kernel(const PlaneSet planes, const eslam_decoders_t dec,
+#ifndef FWD_WAVES
+#define FWD_WAVES 2            // waves per SIMD the gather kernels are compiled for: with one plane of loads in flight
+                               // ahead of the FMAs the forward kernel needs 195 VGPRs; 2 waves/SIMD measured fastest
+#endif
+__global__ __launch_bounds__(256, FWD_WAVES) void render_fwd_kernel(const PlaneSet planes, const eslam_decoders_t dec,
                                                          const Bound bnd, const float* __restrict__ rays_o,
                                                          const float* __restrict__ rays_d,
                                                          const float* __restrict__ z_vals, int R, int S,
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256, 4) void render_fwd_kernel(const PlaneSet plane
 // decode on free points: replaces reference src/networks/decoders.py:127-146 (and :87-105 when SDF_ONLY)
 // ---------------------------------------------------------------------------------------------------------
 template <bool CL, bool SDF_ONLY, bool SAVE>
-__global__ __launch_bounds__(256, 4) void decode_fwd_kernel(const PlaneSet planes, const eslam_decoders_t dec,
+__global__ __launch_bounds__(256, FWD_WAVES) void decode_fwd_kernel(const PlaneSet planes, const eslam_decoders_t dec,
                                                          const Bound bnd, const float* __restrict__ pts, int64_t N,
                                                          float* __restrict__ raw, float* __restrict__ feat_out) {
     __shared__ __attribute__((aligned(16))) float wlds[2 * DEC_LDS];
@@ -173,8 +177,6 @@ __global__ __launch_bounds__(256, 4) void decode_fwd_kernel(const PlaneSet plane
 // ---------------------------------------------------------------------------------------------------------
 bool eslam_planes_channels_last(const eslam_plane_t* planes, int first, int count);
 int eslam_validate_planes(const eslam_plane_t* planes, int first, int count);
-int eslam_ray_order(const float* rays_o, const float* rays_d, int R, int* perm, hipStream_t st);
-
 static Bound make_bound(const float* b6) {
     Bound b;
     for (int k = 0; k < 3; ++k) {
@@ -187,8 +189,8 @@ static Bound make_bound(const float* b6) {
 
 extern "C" int eslam_render_fwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
                                 const float* rays_o, const float* rays_d, const float* z_vals, int R, int S,
-                                float* depth, float* rgb, float* sdf, float* raw_rgb, float* feat, int32_t* ray_order,
-                                eslam_stream_t stream) {
+                                float* depth, float* rgb, float* sdf, float* raw_rgb, float* feat,
+                                const int32_t* ray_order, eslam_stream_t stream) {
     if (R <= 0) return 0;
     if (S <= 0 || S > ESLAM_MAX_SAMPLES) {
         eslam_set_error("eslam_render_fwd: S=%d outside [1,%d]", S, ESLAM_MAX_SAMPLES);
@@ -211,8 +213,6 @@ extern "C" int eslam_render_fwd(const eslam_plane_t* planes, const eslam_decoder
     const int nblocks = (R + 3) / 4;
     dim3 grid(((nblocks + 7) / 8) * 8), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (ray_order)
-        if (int rc = eslam_ray_order(rays_o, rays_d, R, ray_order, st)) return rc;
 #define LAUNCH(CLv, SV)                                                                                             \
     hipLaunchKernelGGL((render_fwd_kernel<CLv, SV>), grid, block, 0, st, ps, *dec, bnd, rays_o, rays_d, z_vals, R, \
                        S, depth, rgb, sdf, raw_rgb, feat, (const int*)ray_order)

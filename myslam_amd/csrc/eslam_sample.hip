@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void sample_z_kernel(const float* __restrict__
 // K4: reference src/utils/Renderer.py:108-134 + src/common.py:41-77.  One wave per zero-depth ray.
 // ---------------------------------------------------------------------------------------------------------
 template <bool CL>
-__global__ __launch_bounds__(256, 4) void importance_z_kernel(const PlaneSet planes, const eslam_decoders_t dec,
+__global__ __launch_bounds__(256, 2) void importance_z_kernel(const PlaneSet planes, const eslam_decoders_t dec,
                                                            const Bound bnd, const float* __restrict__ rays_o,
                                                            const float* __restrict__ rays_d,
                                                            const float* __restrict__ gt_depth, int R, int n_strat,

@@ -337,7 +337,13 @@ static int env_int(const char* name, int dflt) {
 int eslam_scatter_v2_init();
 
 // perm [R] <- rays ordered by direction; chunks of SORT_MAX rays are ordered independently
-int eslam_ray_order(const float* rays_o, const float* rays_d, int R, int* perm, hipStream_t st) {
+extern "C" int eslam_ray_order(const float* rays_o, const float* rays_d, int R, int32_t* perm, eslam_stream_t stream) {
+    if (R <= 0) return 0;
+    if (!rays_o || !rays_d || !perm) {
+        eslam_set_error("eslam_ray_order: null argument");
+        return 1;
+    }
+    hipStream_t st = (hipStream_t)stream;
     if (int rc = eslam_scatter_v2_init()) return rc;
     const int chunks = (R + SORT_MAX - 1) / SORT_MAX;
     hipLaunchKernelGGL(ray_order_kernel, dim3(chunks), dim3(1024), ORD_CELLS * sizeof(unsigned), st, rays_o, rays_d, R,

@@ -103,13 +103,38 @@ def _split_dec_grads(g_dec):
     return out
 
 
-class RenderFn(torch.autograd.Function):
-    """depth, rgb, sdf = RenderFn.apply(rays_o, rays_d, z_vals, bound6, beta, *12 planes, *12 decoder params)
+_side_streams = {}
 
-    Forward = eslam_render_fwd, backward = eslam_render_bwd (reference: Renderer.py:136-147 and its autograd)."""
+
+def ray_order_async(rays_o, rays_d):
+    """Launch eslam_ray_order on a side stream (it depends only on the rays, so it overlaps the samplers).
+    Returns (perm int32 [R], stream to join before the order is used)."""
+    _hip.require_gpu_f32("rays_o", rays_o)
+    _hip.require_gpu_f32("rays_d", rays_d)
+    dev = rays_o.device
+    ro, rd = _c(rays_o.detach()), _c(rays_d.detach())
+    R = ro.shape[0]
+    side = _side_streams.get(dev.index)
+    if side is None:
+        side = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
+    perm = torch.empty(R, dtype=torch.int32, device=dev)
+    cur = torch.cuda.current_stream(dev)
+    side.wait_stream(cur)
+    with torch.cuda.device(dev), torch.cuda.stream(side):
+        _hip.check(_hip.lib().eslam_ray_order(_hip.ptr(ro), _hip.ptr(rd), R, _hip.ptr(perm),
+                                              ctypes.c_void_p(side.cuda_stream)), "eslam_ray_order")
+    perm.record_stream(side)
+    return perm, side
+
+
+class RenderFn(torch.autograd.Function):
+    """depth, rgb, sdf = RenderFn.apply(rays_o, rays_d, z_vals, bound6, beta, order, *12 planes, *12 decoder params)
+
+    Forward = eslam_render_fwd, backward = eslam_render_bwd (reference: Renderer.py:136-147 and its autograd).
+    order = (perm, stream) from ray_order_async, or None."""
 
     @staticmethod
-    def forward(ctx, rays_o, rays_d, z_vals, bound6, beta, *tensors):
+    def forward(ctx, rays_o, rays_d, z_vals, bound6, beta, order_in, *tensors):
         planes, params = tensors[:12], tensors[12:24]
         for n, t in (("rays_o", rays_o), ("rays_d", rays_d), ("z_vals", z_vals)):
             _hip.require_gpu_f32(n, t)
@@ -125,7 +150,10 @@ class RenderFn(torch.autograd.Function):
         sdf = torch.empty(R, S, device=dev)
         raw_rgb = torch.empty(R, S, 3, device=dev) if needs else None
         feat = torch.empty(R * S, 128, device=dev) if needs else None
-        order = torch.empty(R, dtype=torch.int32, device=dev) if needs else None
+        order = None
+        if order_in is not None:
+            order, side = order_in
+            torch.cuda.current_stream(dev).wait_stream(side)
         with torch.cuda.device(dev):
             _hip.check(lib.eslam_render_fwd(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(rays_o),
                                             _hip.ptr(rays_d), _hip.ptr(z_vals), R, S, _hip.ptr(depth), _hip.ptr(rgb),
@@ -145,7 +173,7 @@ class RenderFn(torch.autograd.Function):
         dev = rays_o.device
         lib = _hip.lib()
         need = ctx.needs_input_grad
-        need_planes = any(need[5:17])
+        need_planes = any(need[6:18])
         need_rays = need[0] or need[1]
         grads = None
         sink = _grad_sink
@@ -178,11 +206,11 @@ class RenderFn(torch.autograd.Function):
                        "eslam_render_bwd")
         if sink is not None:
             # the data-parallel caller owns .grad assignment (FlatGrads.assign): hand autograd nothing to accumulate
-            return (g_ro if need[0] else None, g_rd if need[1] else None) + (None,) * 27
+            return (g_ro if need[0] else None, g_rd if need[1] else None) + (None,) * 28
         dec_grads = _split_dec_grads(g_dec)
-        out = [g_ro if need[0] else None, g_rd if need[1] else None, None, None, g_beta if need[4] else None]
-        out += [grads[i] if (need_planes and need[5 + i]) else None for i in range(12)]
-        out += [dec_grads[i] if need[17 + i] else None for i in range(12)]
+        out = [g_ro if need[0] else None, g_rd if need[1] else None, None, None, g_beta if need[4] else None, None]
+        out += [grads[i] if (need_planes and need[6 + i]) else None for i in range(12)]
+        out += [dec_grads[i] if need[18 + i] else None for i in range(12)]
         return tuple(out)
 
 

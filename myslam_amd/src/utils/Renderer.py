@@ -31,13 +31,19 @@ class Renderer(object):
         if n_rays == 0:
             e = rays_o.new_empty
             return e(0), e(0, 3), e(0, S), e(0, S)
+        flat_planes = [p for grp in all_planes for p in grp]
+        # training calls get a direction-sorted ray order (better L2 locality forward, bundling for the scatter); it only
+        # depends on the rays, so it runs on a side stream next to the samplers
+        wants_grad = torch.is_grad_enabled() and (rays_o.requires_grad or rays_d.requires_grad or
+                                                  any(p.requires_grad for p in flat_planes) or
+                                                  any(p.requires_grad for p in decoders.parameters()))
+        order = ops.ray_order_async(rays_o, rays_d) if wants_grad else None
         z_vals = ops.sample_z(rays_o, rays_d, gt_depth, all_planes, decoders, self._bound6, truncation,
                               self.n_stratified, self.n_importance, self.perturb, _rand)
-        flat_planes = [p for grp in all_planes for p in grp]
         beta = ops.beta_tensor(decoders.beta, rays_o.device)
         # pts are normalised with decoders.bound (decoders.py:138), the importance sampler uses renderer.bound
         bound6 = ops.bound_to_host(decoders.bound)
-        depth, rgb, sdf = ops.RenderFn.apply(rays_o, rays_d, z_vals, bound6, beta, *flat_planes,
+        depth, rgb, sdf = ops.RenderFn.apply(rays_o, rays_d, z_vals, bound6, beta, order, *flat_planes,
                                              *ops.decoder_params(decoders))
         return depth, rgb, sdf, z_vals
 
