@@ -138,21 +138,28 @@ __global__ __launch_bounds__(1024) void ray_order_kernel(const float* __restrict
 // ---------------------------------------------------------------------------------------------------------
 // bundle scatter
 // ---------------------------------------------------------------------------------------------------------
-#define BUNDLE_MAX 1024            // samples per workgroup (power of two, 4 per thread)
-
-template <bool RENDER>
-__global__ __launch_bounds__(256) void scatter_sort_kernel(const PlaneSet planes, const Bound bnd,
-                                                           const float* __restrict__ rays_o,
-                                                           const float* __restrict__ rays_d,
-                                                           const float* __restrict__ z_vals,     // RENDER ? [R,S] : pts [N,3]
-                                                           const int* __restrict__ perm, int R, int S,
-                                                           const float* __restrict__ g_feat, int bundle, int dbg_mode) {
-    __shared__ unsigned skey[BUNDLE_MAX];          // (cell << 10) | local sample slot, sorted
-    __shared__ unsigned sxy[BUNDLE_MAX];           // per slot: x0 | y0 << 12 | (x1 > x0) << 24 | (y1 > y0) << 25
-    __shared__ float swx[BUNDLE_MAX], swy[BUNDLE_MAX];   // per slot: bilinear fractions
-    __shared__ int sgrow[BUNDLE_MAX];              // per slot: row of g_feat (global point index)
+// NT threads per workgroup, BM = 4*NT samples per workgroup (power of two).
+//   DBG: 0 production; 1 walk without atomics; 2 stop after the sort (profiling only, tools/dbg_scatter.py)
+template <bool RENDER, int DBG, int NT>
+__global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes, const Bound bnd,
+                                                          const float* __restrict__ rays_o,
+                                                          const float* __restrict__ rays_d,
+                                                          const float* __restrict__ z_vals,     // RENDER ? [R,S] : pts [N,3]
+                                                          const int* __restrict__ perm, int R, int S,
+                                                          const float* __restrict__ g_feat, int bundle) {
+    constexpr int dbg_mode = DBG;
+    constexpr int BM = 4 * NT;
+    constexpr int SLOT_BITS = (BM == 1024) ? 10 : 11;
+    constexpr unsigned SLOT_MASK = BM - 1;
+    static_assert(BM == 1024 || BM == 2048, "bundle size");
+    __shared__ unsigned skey[BM];          // (cell << SLOT_BITS) | local sample slot, sorted
+    __shared__ unsigned sxy[BM];           // per slot: byte offset of texel (x0,y0) | minor-axis step flag | major flag << 1
+                                           // (offsets are multiples of 4: the two low bits are free)
+    __shared__ float stm[BM], stM[BM];     // per slot: bilinear fraction along the minor / major axis
+    __shared__ int sgrow[BM];              // per slot: row of g_feat (global point index)
+    __shared__ int sbox[4];                // bounding box of the bundle's cells: xmin, xmax, ymin, ymax
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int hx = lane >> 5, c = lane & 31;
+    const int hx = lane >> 5, c = lane & 31;   // hx: corner along the MINOR axis
 
     const int pi = blockIdx.y;                               // plane index in all_planes order
     const int d = pi / 6, o = (pi % 6) >> 1, lvl = pi & 1;
@@ -165,11 +172,19 @@ __global__ __launch_bounds__(256) void scatter_sort_kernel(const PlaneSet planes
     const int per = RENDER ? S : 64;                                  // samples per unit
     const int u0 = blockIdx.x * bundle;
     const int nu = min(bundle, nunits - u0);
-    const int n = nu * per;                                           // <= BUNDLE_MAX by construction of `bundle`
+    const int n = nu * per;                                           // <= BM by construction of `bundle`
 
-    // (1) cells
-    for (int slot = threadIdx.x; slot < BUNDLE_MAX; slot += 256) {
-        unsigned key = 0xFFFFFFFFu;
+    if (threadIdx.x == 0) { sbox[0] = 0x7FFFFFFF; sbox[1] = -1; sbox[2] = 0x7FFFFFFF; sbox[3] = -1; }
+    __syncthreads();
+
+    // (1) bilinear cell of every sample of the bundle (4 per thread), and the bundle's bounding box in the plane
+    AxisCoord cax[4], cay[4];
+    int cpt[4];
+    int bx0 = 0x7FFFFFFF, bx1 = -1, by0 = 0x7FFFFFFF, by1 = -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int slot = threadIdx.x + k * NT;
+        cpt[k] = -1;
         if (slot < n) {
             const int ui = u0 + slot / per, s = slot % per;
             const int unit = (RENDER && perm) ? perm[ui] : ui;
@@ -187,31 +202,58 @@ __global__ __launch_bounds__(256) void scatter_sort_kernel(const PlaneSet planes
                 x = norm_coord(x, bnd.lo[0], bnd.hi[0]);
                 y = norm_coord(y, bnd.lo[1], bnd.hi[1]);
                 z = norm_coord(z, bnd.lo[2], bnd.hi[2]);
-                const AxisCoord ax = axis_coord((o == 2) ? y : x, pw);
-                const AxisCoord ay = axis_coord((o == 0) ? y : z, ph);
-                key = ((unsigned)(ay.i0 * pw + ax.i0) << 10) | (unsigned)slot;
-                sxy[slot] = (unsigned)ax.i0 | ((unsigned)ay.i0 << 12) | ((unsigned)(ax.i1 > ax.i0) << 24) |
-                            ((unsigned)(ay.i1 > ay.i0) << 25);
-                swx[slot] = ax.t;
-                swy[slot] = ay.t;
-                sgrow[slot] = (int)pt;
+                cax[k] = axis_coord((o == 2) ? y : x, pw);
+                cay[k] = axis_coord((o == 0) ? y : z, ph);
+                cpt[k] = (int)pt;
+                bx0 = min(bx0, cax[k].i0); bx1 = max(bx1, cax[k].i0);
+                by0 = min(by0, cay[k].i0); by1 = max(by1, cay[k].i0);
             }
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        bx0 = min(bx0, __shfl_xor(bx0, m, WAVE)); bx1 = max(bx1, __shfl_xor(bx1, m, WAVE));
+        by0 = min(by0, __shfl_xor(by0, m, WAVE)); by1 = max(by1, __shfl_xor(by1, m, WAVE));
+    }
+    if (lane == 0) {
+        atomicMin(&sbox[0], bx0); atomicMax(&sbox[1], bx1);
+        atomicMin(&sbox[2], by0); atomicMax(&sbox[3], by1);
+    }
+    __syncthreads();
+    // The sort key runs along the axis the bundle travels along ("minor" = fastest-varying), so that consecutive cells
+    // of the sorted list are neighbours along it and share a texel column that is carried instead of flushed twice.
+    const bool swap = (sbox[3] - sbox[2]) > (sbox[1] - sbox[0]);      // travels along y: column-major keys
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int slot = threadIdx.x + k * NT;
+        unsigned key = 0xFFFFFFFFu;
+        if (cpt[k] >= 0) {
+            const AxisCoord& am = swap ? cay[k] : cax[k];       // minor axis
+            const AxisCoord& aM = swap ? cax[k] : cay[k];       // major axis
+            const int cell = aM.i0 * (swap ? ph : pw) + am.i0;
+            key = ((unsigned)cell << SLOT_BITS) | (unsigned)slot;
+            sxy[slot] = ((unsigned)(cay[k].i0 * psy + cax[k].i0 * psx) << 2) | (unsigned)(am.i1 > am.i0) |
+                        ((unsigned)(aM.i1 > aM.i0) << 1);
+            stm[slot] = am.t;
+            stM[slot] = aM.t;
+            sgrow[slot] = cpt[k];
         }
         skey[slot] = key;
     }
     __syncthreads();
+
     // (2) bitonic sort of the keys (invalid slots carry the maximum key and end up last).  Wave w owns elements
     // [256w, 256w+256): every compare-exchange distance j < 256 stays inside one wave's chunk and needs no workgroup
-    // barrier (DS operations of a wave execute in order); only the 3 stages with j >= 256 synchronise the workgroup.
+    // barrier (DS operations of a wave execute in order); only the stages with j >= 256 synchronise the workgroup.
     {
-        const int wbase = wave * (BUNDLE_MAX / 4);
-        for (int k = 2; k <= BUNDLE_MAX; k <<= 1) {
+        const int wbase = wave * 256;
+        for (int k = 2; k <= BM; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
-                if (j >= BUNDLE_MAX / 4) {
+                if (j >= 256) {
                     __syncthreads();
 #pragma unroll
-                    for (int t = 0; t < BUNDLE_MAX / 512; ++t) {
-                        const int p = threadIdx.x + t * 256;                      // pair index
+                    for (int t = 0; t < 2; ++t) {
+                        const int p = threadIdx.x + t * NT;                       // pair index
                         const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));      // lower element of the pair
                         const int l = i | j;
                         const unsigned a = skey[i], b2 = skey[l];
@@ -220,7 +262,7 @@ __global__ __launch_bounds__(256) void scatter_sort_kernel(const PlaneSet planes
                     __syncthreads();
                 } else {
 #pragma unroll
-                    for (int t = 0; t < BUNDLE_MAX / 512; ++t) {
+                    for (int t = 0; t < 2; ++t) {
                         const int p = lane + t * WAVE;                            // pair index inside the wave's chunk
                         const int i = wbase + (((p & ~(j - 1)) << 1) | (p & (j - 1)));
                         const int l = i | j;
@@ -232,43 +274,50 @@ __global__ __launch_bounds__(256) void scatter_sort_kernel(const PlaneSet planes
             }
         }
     }
-    if (dbg_mode == 2) return;      // profiling only (tools/dbg_scatter.py): cost of phases 1+2
+    if (dbg_mode == 2) return;
 
     // (3) walk: wave w owns sorted entries [256w, 256w+256), 64 at a time.  Every lane fetches ONE entry's record from
-    // LDS (cell, g_feat row, fractions); the walk reads records with v_readlane.  The g_feat values of 32 entries are
-    // loaded ahead of the walk of the previous 32: a wave's loads, stores and atomics retire in order on one vmcnt
-    // counter, so a load issued BEHIND an atomic would wait for it (~3000 cycles under load); issued ahead of them, the
-    // loads only ever wait for other loads.
-    const float* __restrict__ gcol = g_feat + d * 64 + lvl * 32 + c;
-    const int DUMMY = 0x3FFFFF;                    // cell of padding entries: never flushed
+    // LDS (cell, g_feat row, fractions); the walk reads records with v_readlane.  The g_feat values of WALK_N entries
+    // are loaded ahead of the walk of the previous WALK_N: a wave's loads, stores and atomics retire in order on one
+    // vmcnt counter, so a load issued BEHIND an atomic would wait for it (~3000 cycles under load).
+    const char* __restrict__ gcol = (const char*)(g_feat + d * 64 + lvl * 32);     // + row * 512 + c * 4 bytes
+    constexpr int DUMMY = (int)(0xFFFFFFFFu >> SLOT_BITS);     // cell of padding entries: never flushed
     int cur_cell = -1;
     unsigned cur_xy = 0;
     float acc0 = 0.f, acc1 = 0.f;
-    const int e0 = wave * (BUNDLE_MAX / 4);
+    const int e0 = wave * 256;
 
-    auto flush = [&]() {
+    // Flush of a finished cell: lane (hx, c) adds its two sums (major-axis corners 0 and 1) for its minor-axis corner.
+    // All addressing is 32-bit VALU arithmetic on a byte offset from the wave-uniform plane base (SGPR base + VGPR
+    // offset form): a first version did 64-bit address arithmetic on the scalar unit, and with 32 waves per CU sharing
+    // ONE scalar ALU the walk was SALU-bound (11 scalar instructions per entry).
+    const unsigned lane_off = (unsigned)(c * psc) << 2;
+    const unsigned dm_bytes = (unsigned)(swap ? psy : psx) << 2, dM_bytes = (unsigned)(swap ? psx : psy) << 2;
+    char* __restrict__ gbytes = (char*)grad;
+    auto flush = [&](bool lower_half_only) {
         if (cur_cell >= 0 && cur_cell != DUMMY) {
-            const int x0 = cur_xy & 0xFFF, y0 = (cur_xy >> 12) & 0xFFF;
-            const int dxs = ((cur_xy >> 24) & 1) * psx, dys = ((cur_xy >> 25) & 1) * psy;
-            float* gp = grad + y0 * psy + x0 * psx + hx * dxs + c * psc;
+            const unsigned o0 = (cur_xy & ~3u) + lane_off + ((cur_xy & 1u) & (unsigned)hx) * dm_bytes;
+            const unsigned o1 = o0 + ((cur_xy >> 1) & 1u) * dM_bytes;
             if (dbg_mode != 1) {
-                atomicAdd(gp, acc0);
-                atomicAdd(gp + dys, acc1);
-            } else if (acc0 == 1.2345e30f) gp[0] = acc1;      // profiling only: walk without atomics
+                if (!lower_half_only || hx == 0) {
+                    atomicAdd((float*)(gbytes + o0), acc0);
+                    atomicAdd((float*)(gbytes + o1), acc1);
+                }
+            } else if (acc0 == 1.2345e30f) *(float*)(gbytes + o0) = acc1;      // profiling only: walk without atomics
         }
     };
 
-    struct Rec { int cell, row; unsigned xy; float tx, ty; };
+    struct Rec { int cell, row; unsigned xy; float tm, tM; };
     auto fetch = [&](int blk) {
         Rec r;
         const unsigned k = skey[e0 + blk * WAVE + lane];
         const bool valid = k != 0xFFFFFFFFu;
-        const int slot = k & 1023u;
-        r.cell = valid ? (int)(k >> 10) : DUMMY;
+        const int slot = k & SLOT_MASK;
+        r.cell = valid ? (int)(k >> SLOT_BITS) : DUMMY;
         r.row = valid ? sgrow[slot] : 0;
         r.xy = valid ? sxy[slot] : 0u;
-        r.tx = valid ? swx[slot] : 0.f;
-        r.ty = valid ? swy[slot] : 0.f;
+        r.tm = valid ? stm[slot] : 0.f;
+        r.tM = valid ? stM[slot] : 0.f;
         return r;
     };
 #ifndef WALK_N
@@ -276,29 +325,37 @@ __global__ __launch_bounds__(256) void scatter_sort_kernel(const PlaneSet planes
 #endif
 #define LOAD_HALF(buf, rec, half)                                                             \
     _Pragma("unroll") for (int t = 0; t < WALK_N; ++t) {                                      \
-        const int row = __builtin_amdgcn_readlane((rec).row, (half) * WALK_N + t);            \
-        buf[t] = gcol[(int64_t)row * 128];                                                    \
+        const unsigned row = (unsigned)__builtin_amdgcn_readlane((rec).row, (half) * WALK_N + t); \
+        buf[t] = *(const float*)(gcol + (row * 512u + (unsigned)c * 4u));                     \
     }
 #define WALK_HALF(buf, rec, half)                                                             \
     _Pragma("unroll") for (int t = 0; t < WALK_N; ++t) {                                      \
         const int idx = (half) * WALK_N + t;                                                  \
         const int cell = __builtin_amdgcn_readlane((rec).cell, idx);                          \
         if (cell != cur_cell) {                                                               \
-            flush();                                                                          \
+            if (cell == cur_cell + 1 && (cur_xy & 1u)) {                                      \
+                /* next cell along the minor axis: its first texel column is our second one - keep those sums */ \
+                flush(true);                                                                  \
+                const float s0 = __shfl_xor(acc0, 32, WAVE), s1 = __shfl_xor(acc1, 32, WAVE); \
+                acc0 = hx ? 0.f : s0;                                                         \
+                acc1 = hx ? 0.f : s1;                                                         \
+            } else {                                                                          \
+                flush(false);                                                                 \
+                acc0 = 0.f;                                                                   \
+                acc1 = 0.f;                                                                   \
+            }                                                                                 \
             cur_cell = cell;                                                                  \
             cur_xy = (unsigned)__builtin_amdgcn_readlane((int)(rec).xy, idx);                 \
-            acc0 = 0.f;                                                                       \
-            acc1 = 0.f;                                                                       \
         }                                                                                     \
-        const float tx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (rec).tx), idx)); \
-        const float ty = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (rec).ty), idx)); \
-        const float wx = hx ? tx : 1.0f - tx;                                                 \
-        const float g = (cell != DUMMY) ? buf[t] : 0.0f;                                      \
-        acc0 += g * (wx * (1.0f - ty));                                                       \
-        acc1 += g * (wx * ty);                                                                \
+        const float tm = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (rec).tm), idx)); \
+        const float tM = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (rec).tM), idx)); \
+        const float wm = hx ? tm : 1.0f - tm;                                                 \
+        const float g = buf[t];        /* padding entries accumulate into the DUMMY run, which is never flushed */ \
+        acc0 += g * (wm * (1.0f - tM));                                                       \
+        acc1 += g * (wm * tM);                                                                \
     }
 
-    const int nblk = BUNDLE_MAX / 4 / WAVE;
+    const int nblk = 256 / WAVE;
     const int ngrp = WAVE / WALK_N;                 // groups per 64-entry record block (even)
     float ga[WALK_N], gb[WALK_N];
     Rec rec = fetch(0);
@@ -323,7 +380,7 @@ __global__ __launch_bounds__(256) void scatter_sort_kernel(const PlaneSet planes
     }
 #undef LOAD_HALF
 #undef WALK_HALF
-    flush();
+    flush(false);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -358,25 +415,48 @@ int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float*
     PlaneSet ps;
     for (int i = 0; i < NPL; ++i) {
         ps.p[i] = planes[i];
-        if (planes[i].w > 4096 || planes[i].h > 4096 || (int64_t)planes[i].w * planes[i].h >= (1 << 22)) {
-            eslam_set_error("scatter: plane %d is %d x %d, the cell key supports up to 4096 per side and 2^22 cells", i,
-                            planes[i].h, planes[i].w);
-            return 1;
-        }
+
     }
     const int64_t N = render ? R * S : R;
     const int nunits = render ? (int)R : (int)((N + 63) / 64);
+    // the walk addresses g_feat rows and plane texels with 32-bit byte offsets from a uniform base
+    if (N * 512 >= ((int64_t)1 << 32)) {
+        eslam_set_error("scatter: %lld points exceed the 32-bit offset range of the feature-gradient buffer (8.3 M): split "
+                        "the batch", (long long)N);
+        return 1;
+    }
+    for (int i = 0; i < NPL; ++i) {
+        const int64_t extent = (ESLAM_C_DIM - 1) * planes[i].stride_c + (int64_t)(planes[i].h - 1) * planes[i].stride_y +
+                               (int64_t)(planes[i].w - 1) * planes[i].stride_x + 1;
+        if (extent >= ((int64_t)1 << 30)) {
+            eslam_set_error("scatter: plane %d spans %lld elements, limit 2^30", i, (long long)extent);
+            return 1;
+        }
+    }
     static const int nosort = env_int("ESLAM_SC_NOSORT", 0), dbg_mode = env_int("ESLAM_SC_MODE", 0);       // A/B switch for profiling only
     if (nosort) perm = nullptr;
     const int per = render ? S : 64;
-    const int bundle = BUNDLE_MAX / per;          // S <= ESLAM_MAX_SAMPLES = 256 -> at least 4 rays
-    dim3 grid((nunits + bundle - 1) / bundle, NPL), block(256);
-    if (render)
-        hipLaunchKernelGGL((scatter_sort_kernel<true>), grid, block, 0, st, ps, bnd, rays_o, rays_d, z_or_pts,
-                           perm, (int)R, S, g_feat, bundle, dbg_mode);
-    else
-        hipLaunchKernelGGL((scatter_sort_kernel<false>), grid, block, 0, st, ps, bnd, rays_o, rays_d, z_or_pts,
-                           (const int*)nullptr, (int)R, 64, g_feat, bundle, dbg_mode);
+    // 2048 samples per workgroup (512 threads) halve the number of cell flushes of 1024; S up to 256 -> >= 8 rays
+    static const int bm = env_int("ESLAM_SC_BUNDLE", 2048);        // profiling switch: 1024 or 2048
+    for (int i = 0; i < NPL; ++i)
+        if ((int64_t)planes[i].w * planes[i].h >= ((1 << 21) - 2)) {
+            eslam_set_error("scatter: plane %d has %d x %d cells, limit 2^21", i, planes[i].h, planes[i].w);
+            return 1;
+        }
+    const int bundle = (bm == 1024 ? 1024 : 2048) / per;
+    dim3 grid((nunits + bundle - 1) / bundle, NPL);
+#define LAUNCH_SC(RD, DB, NTv, PERM, SS)                                                                               \
+    hipLaunchKernelGGL((scatter_sort_kernel<RD, DB, NTv>), grid, dim3(NTv), 0, st, ps, bnd, rays_o, rays_d, z_or_pts, \
+                       PERM, (int)R, SS, g_feat, bundle)
+    if (render) {
+        if (dbg_mode == 1) LAUNCH_SC(true, 1, 512, perm, S);
+        else if (dbg_mode == 2) LAUNCH_SC(true, 2, 512, perm, S);
+        else if (bm == 1024) LAUNCH_SC(true, 0, 256, perm, S);
+        else LAUNCH_SC(true, 0, 512, perm, S);
+    } else {
+        LAUNCH_SC(false, 0, 512, (const int*)nullptr, 64);
+    }
+#undef LAUNCH_SC
     return eslam_check_launch("scatter_sort_kernel");
 }
 
