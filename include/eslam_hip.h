@@ -166,7 +166,8 @@ int eslam_mapping_loss(const float* depth, const float* rgb, const float* sdf, c
  * eslam_loss_reduce on its shard, the ESLAM_LOSS_ACC floats of `acc` (set sizes and squared-error sums) are
  * summed over ranks with one tiny all-reduce, then eslam_loss_grad produces upstream gradients scaled by the GLOBAL
  * set sizes, so the summed gradients equal those of the unsharded batch.  acc must be zeroed by the caller
- * before eslam_loss_reduce (it accumulates).                                                               */
+ * before eslam_loss_reduce (it accumulates).  eslam_loss_grad: loss, g_* may be NULL when not wanted; `upstream`
+ * (device scalar, optional) multiplies the gradients - the grad_output autograd hands to the loss's backward.    */
 #define ESLAM_LOSS_ACC 16
 int eslam_loss_reduce(const float* depth, const float* rgb, const float* sdf, const float* z_vals,
                       const float* gt_depth, const float* gt_color, int R, int S, double truncation,
@@ -174,7 +175,7 @@ int eslam_loss_reduce(const float* depth, const float* rgb, const float* sdf, co
 int eslam_loss_grad(const float* depth, const float* rgb, const float* sdf, const float* z_vals,
                     const float* gt_depth, const float* gt_color, int R, int S, double truncation,
                     const float* weights5_host, const uint8_t* ray_mask, const float* acc, float* loss,
-                    float* g_depth, float* g_rgb, float* g_sdf, eslam_stream_t stream);
+                    float* g_depth, float* g_rgb, float* g_sdf, const float* upstream, eslam_stream_t stream);
 
 /* Per-kernel device timing for bench.py's roofline line (HIP events recorded on the launch stream around each
  * kernel while enabled; adds nothing to the launch path when disabled).  Usage: enable(1); run one iteration;

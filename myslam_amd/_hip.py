@@ -57,7 +57,7 @@ SIGNATURES = {
     "eslam_profile_enable": (_i, [_i]),
     "eslam_profile_read": (_i, [_BP]),
     "eslam_profile_name": (ctypes.c_char_p, [_i]),
-    "eslam_loss_grad": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _BP, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "eslam_loss_grad": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _BP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -71,18 +71,24 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
                                                         const float* __restrict__ gt_depth,
                                                         const float* __restrict__ gt_color,
                                                         const uint8_t* __restrict__ ray_mask, int R, int S, const Trunc tr,
-                                                        const LossW w, const float* __restrict__ acc,
+                                                        const LossW w_in, const float* __restrict__ acc,
                                                         float* __restrict__ loss, float* __restrict__ g_depth,
-                                                        float* __restrict__ g_rgb, float* __restrict__ g_sdf) {
+                                                        float* __restrict__ g_rgb, float* __restrict__ g_sdf,
+                                                        const float* __restrict__ upstream) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ray = blockIdx.x * 4 + wave;
     const float nf = acc[A_N_FRONT], nc = acc[A_N_CENTER], nt = acc[A_N_TAIL], nd = acc[A_N_DEPTH], ncol = acc[A_N_COLOR];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    LossW w = w_in;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && loss) {
         // torch.mean over an empty set is NaN (0/0); keep that behaviour
         loss[0] = w.fs * (acc[A_S_FRONT] / nf) + w.center * (acc[A_S_CENTER] / nc) + w.tail * (acc[A_S_TAIL] / nt) +
                   w.color * (acc[A_S_COLOR] / ncol) + w.depth * (acc[A_S_DEPTH] / nd);
     }
-    if (ray >= R) return;
+    if (ray >= R || !g_sdf) return;
+    if (upstream) {
+        const float u = upstream[0];
+        w.fs *= u; w.center *= u; w.tail *= u; w.depth *= u; w.color *= u;
+    }
     const float d = gt_depth[ray];
     const bool m = ray_mask ? (ray_mask[ray] != 0) : (d > 0.0f);
     const bool mc = ray_mask ? m : true;
@@ -133,15 +139,18 @@ extern "C" int eslam_loss_reduce(const float* depth, const float* rgb, const flo
 extern "C" int eslam_loss_grad(const float* depth, const float* rgb, const float* sdf, const float* z_vals,
                                const float* gt_depth, const float* gt_color, int R, int S, double truncation,
                                const float* weights5_host, const uint8_t* ray_mask, const float* acc, float* loss,
-                               float* g_depth, float* g_rgb, float* g_sdf, eslam_stream_t stream) {
+                               float* g_depth, float* g_rgb, float* g_sdf, const float* upstream,
+                               eslam_stream_t stream) {
     if (!loss_args_ok("eslam_loss_grad", depth, rgb, sdf, z_vals, gt_depth, gt_color, R, S)) return 1;
-    if (!weights5_host || !acc || !loss || !g_depth || !g_rgb || !g_sdf) {
-        eslam_set_error("eslam_loss_grad: null argument");
+    if (!weights5_host || !acc || (!loss && !g_sdf) || ((g_depth == nullptr) != (g_sdf == nullptr)) ||
+        ((g_rgb == nullptr) != (g_sdf == nullptr))) {
+        eslam_set_error("eslam_loss_grad: null argument (give loss and/or all three gradient buffers)");
         return 1;
     }
     const LossW w = {weights5_host[0], weights5_host[1], weights5_host[2], weights5_host[3], weights5_host[4]};
     hipLaunchKernelGGL(loss_grad_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, depth, rgb, sdf, z_vals,
-                       gt_depth, gt_color, ray_mask, R, S, make_trunc(truncation), w, acc, loss, g_depth, g_rgb, g_sdf);
+                       gt_depth, gt_color, ray_mask, R, S, make_trunc(truncation), w, acc, loss, g_depth, g_rgb, g_sdf,
+                       upstream);
     return eslam_check_launch("loss_grad_kernel");
 }
 
@@ -163,7 +172,7 @@ extern "C" int eslam_mapping_loss(const float* depth, const float* rgb, const fl
                                    (float*)scratch, stream))
         return rc;
     const int rc = eslam_loss_grad(depth, rgb, sdf, z_vals, gt_depth, gt_color, R, S, truncation, weights5_host,
-                                   ray_mask, (const float*)scratch, loss, g_depth, g_rgb, g_sdf, stream);
+                                   ray_mask, (const float*)scratch, loss, g_depth, g_rgb, g_sdf, nullptr, stream);
     eslam_prof_end(PROF_LOSS, (hipStream_t)stream);
     return rc;
 }

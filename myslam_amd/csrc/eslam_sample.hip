@@ -207,6 +207,14 @@ __global__ __launch_bounds__(256, 2) void importance_z_kernel(const PlaneSet pla
     __shared__ float zu_all[4][ESLAM_MAX_SAMPLES];      // jittered uniform samples, then the merged list
     __shared__ float wt_all[4][ESLAM_MAX_SAMPLES];      // weights -> cdf
     __shared__ float zn_all[4][ESLAM_MAX_SAMPLES];      // importance samples
+    {   // most batches have no depth-less ray at all: leave before the 11 KB of weights are staged
+        bool any = false;
+        for (int w = 0; w < 4; ++w) {
+            const int rr = blockIdx.x * 4 + w;
+            any |= (rr < R) && !(gt_depth[rr] > 0.0f);
+        }
+        if (!any) return;                                // uniform over the workgroup
+    }
     stage_decoder_weights(wlds, dec, threadIdx.x, blockDim.x);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -393,12 +393,15 @@ def sample_z(rays_o, rays_d, gt_depth, all_planes, decoders, bound6, truncation,
 
 
 class MappingLossFn(torch.autograd.Function):
-    """loss = MappingLossFn.apply(depth, rgb, sdf, z_vals, gt_depth, gt_color, truncation, weights5, ray_mask)
+    """loss = MappingLossFn.apply(depth, rgb, sdf, z_vals, gt_depth, gt_color, truncation, weights5, ray_mask, group)
 
-    Fused restatement of Mapper.py:110-144,337-346 (ray_mask None) / Tracker.py:114-148,197-204 (ray_mask given)."""
+    Fused restatement of Mapper.py:110-144,337-346 (ray_mask None) / Tracker.py:114-148,197-204 (ray_mask given).
+    forward = eslam_loss_reduce (+ the loss value); backward = eslam_loss_grad scaled by the upstream gradient inside the
+    kernel.  `group`: a torch.distributed process group (or True for the default group) makes the set sizes and error
+    sums global with one 16-float all-reduce, for ray-sharded data parallelism (myslam_amd/parallel.py)."""
 
     @staticmethod
-    def forward(ctx, depth, rgb, sdf, z_vals, gt_depth, gt_color, truncation, weights5, ray_mask):
+    def forward(ctx, depth, rgb, sdf, z_vals, gt_depth, gt_color, truncation, weights5, ray_mask, group=None):
         for n, t in (("depth", depth), ("rgb", rgb), ("sdf", sdf), ("z_vals", z_vals), ("gt_depth", gt_depth),
                      ("gt_color", gt_color)):
             _hip.require_gpu_f32(n, t)
@@ -408,20 +411,39 @@ class MappingLossFn(torch.autograd.Function):
         if ray_mask is not None:
             ray_mask = _c(ray_mask.to(torch.uint8))
         loss = torch.empty(1, device=dev)
-        g_depth = torch.empty(R, device=dev)
-        g_rgb = torch.empty(R, 3, device=dev)
-        g_sdf = torch.empty(R, S, device=dev)
-        scratch = torch.empty(16, device=dev)
+        acc = torch.zeros(16, device=dev)
         w = (ctypes.c_float * 5)(*[float(v) for v in weights5])
+        ptrs = [_hip.ptr(t) for t in args]
+        lib = _hip.lib()
         with torch.cuda.device(dev):
-            _hip.check(_hip.lib().eslam_mapping_loss(*[_hip.ptr(t) for t in args], R, S, float(truncation), w, 0,
-                                                     _hip.ptr(ray_mask), _hip.ptr(loss), _hip.ptr(g_depth),
-                                                     _hip.ptr(g_rgb), _hip.ptr(g_sdf), _hip.ptr(scratch),
-                                                     _hip.stream_handle(dev)), "eslam_mapping_loss")
-        ctx.save_for_backward(g_depth, g_rgb, g_sdf)
+            _hip.check(lib.eslam_loss_reduce(*ptrs, R, S, float(truncation), _hip.ptr(ray_mask), _hip.ptr(acc),
+                                             _hip.stream_handle(dev)), "eslam_loss_reduce")
+        if group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=None if group is True else group)
+        with torch.cuda.device(dev):
+            _hip.check(lib.eslam_loss_grad(*ptrs, R, S, float(truncation), w, _hip.ptr(ray_mask), _hip.ptr(acc),
+                                           _hip.ptr(loss), None, None, None, None, _hip.stream_handle(dev)),
+                       "eslam_loss_grad(value)")
+        ctx.save_for_backward(*args, acc)
+        ctx.ray_mask = ray_mask
+        ctx.consts = (float(truncation), tuple(float(v) for v in weights5))
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
-        g_depth, g_rgb, g_sdf = torch._foreach_mul(list(ctx.saved_tensors), g)      # one launch instead of three
-        return g_depth, g_rgb, g_sdf, None, None, None, None, None, None
+        *args, acc = ctx.saved_tensors
+        dev = acc.device
+        R, S = args[2].shape
+        truncation, weights5 = ctx.consts
+        g_depth = torch.empty(R, device=dev)
+        g_rgb = torch.empty(R, 3, device=dev)
+        g_sdf = torch.empty(R, S, device=dev)
+        w = (ctypes.c_float * 5)(*weights5)
+        g = _c(g.detach().reshape(1).to(torch.float32))
+        with torch.cuda.device(dev):
+            _hip.check(_hip.lib().eslam_loss_grad(*[_hip.ptr(t) for t in args], R, S, truncation, w,
+                                                  _hip.ptr(ctx.ray_mask), _hip.ptr(acc), None, _hip.ptr(g_depth),
+                                                  _hip.ptr(g_rgb), _hip.ptr(g_sdf), _hip.ptr(g),
+                                                  _hip.stream_handle(dev)), "eslam_loss_grad")
+        return g_depth, g_rgb, g_sdf, None, None, None, None, None, None, None

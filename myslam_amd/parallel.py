@@ -57,40 +57,6 @@ class FlatGrads:
             p.grad = v
 
 
-class ShardedLossFn(torch.autograd.Function):
-    """mapping_loss with global denominators: reduce phase -> all-reduce of the accumulators -> gradient phase."""
-
-    @staticmethod
-    def forward(ctx, depth, rgb, sdf, z_vals, gt_depth, gt_color, truncation, weights5, group):
-        import ctypes
-        dev = depth.device
-        R, S = sdf.shape
-        lib = _hip.lib()
-        args = [t.detach().contiguous() for t in (depth, rgb, sdf, z_vals, gt_depth, gt_color)]
-        acc = torch.zeros(16, device=dev)
-        loss = torch.empty(1, device=dev)
-        g_depth = torch.empty(R, device=dev)
-        g_rgb = torch.empty(R, 3, device=dev)
-        g_sdf = torch.empty(R, S, device=dev)
-        w = (ctypes.c_float * 5)(*[float(v) for v in weights5])
-        ptrs = [_hip.ptr(t) for t in args]
-        with torch.cuda.device(dev):
-            _hip.check(lib.eslam_loss_reduce(*ptrs, R, S, float(truncation), None, _hip.ptr(acc),
-                                             _hip.stream_handle(dev)), "eslam_loss_reduce")
-        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
-        with torch.cuda.device(dev):
-            _hip.check(lib.eslam_loss_grad(*ptrs, R, S, float(truncation), w, None, _hip.ptr(acc), _hip.ptr(loss),
-                                           _hip.ptr(g_depth), _hip.ptr(g_rgb), _hip.ptr(g_sdf),
-                                           _hip.stream_handle(dev)), "eslam_loss_grad")
-        ctx.save_for_backward(g_depth, g_rgb, g_sdf)
-        return loss[0]
-
-    @staticmethod
-    def backward(ctx, g):
-        g_depth, g_rgb, g_sdf = torch._foreach_mul(list(ctx.saved_tensors), g)
-        return g_depth, g_rgb, g_sdf, None, None, None, None, None, None
-
-
 class ShardedMapper:
     """Drives one ray-sharded mapping iteration on this rank's shard (a harness.Workload holding this rank's rays)."""
 
@@ -113,8 +79,8 @@ class ShardedMapper:
         with ops.grad_sink(self.grads):
             depth, color, sdf, z = wl.renderer.render_batch_ray(wl.planes, wl.decoders, wl.rays_d, wl.rays_o, wl.device,
                                                                 wl.truncation, gt_depth=wl.gt_depth)
-            loss = ShardedLossFn.apply(depth, color, sdf, z, wl.gt_depth, wl.gt_color, wl.truncation, self.weights,
-                                       self.group)
+            loss = ops.MappingLossFn.apply(depth, color, sdf, z, wl.gt_depth, wl.gt_color, wl.truncation, self.weights,
+                                           None, True if self.group is None else self.group)
             loss.backward()
         self.grads.all_reduce(self.group)
         self.grads.assign()
