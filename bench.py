@@ -68,6 +68,7 @@ def kernel_profile(step_fn, iters):
 def cpu_baseline(wl, budget_s=25.0, max_iters=5):
     """Oracle on the host cores: forward + mapping loss + backward on the same rays / planes / decoders."""
     from oracle import eslam_oracle as orc
+    orc.BILINEAR_IMPL = "grid_sample"          # the torch op the reference itself calls (decoders.py:79-81)
     # the GPU box gives a 1-GPU job a 16-CPU share of a 256-thread host: more torch threads than that oversubscribe
     ncpu = min(len(os.sched_getaffinity(0)), int(os.environ.get("BENCH_CPU_THREADS", "16")))
     torch.set_num_threads(max(1, ncpu))
@@ -95,8 +96,42 @@ def cpu_baseline(wl, budget_s=25.0, max_iters=5):
             break
     t = sorted(times)[len(times) // 2]
     return {"value": wl.R * wl.S / t, "unit": "ray.samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times)} full iterations of the same {wl.R}x{wl.S} workload (median), torch CPU float32, "
+            "sample": f"{len(times)} full iterations of the same {wl.R}x{wl.S} workload (median), torch CPU float32 with "
+                      f"F.grid_sample as in the reference, "
                       f"{t * 1e3:.0f} ms/iter"}
+
+
+def torch_gpu_baseline(wl, iters=10, warmup=3):
+    """The same restatement of the reference's PyTorch-op path, run with torch ops on THIS GPU (boolean-mask loss, autograd
+    through ~2000 small kernels): what a user of the reference gets on one MI355X without this library.  Context for the
+    north_star's ">= 10x the reference single-GPU PyTorch path" target; not the metric."""
+    from oracle import eslam_oracle as orc
+    orc.BILINEAR_IMPL = "grid_sample"
+    dev = wl.device
+    planes = tuple([p.detach().contiguous().clone().requires_grad_(True) for p in grp] for grp in wl.planes)   # NCHW
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in wl.decoders.state_dict().items() if k != "beta"}
+    beta = wl.decoders.beta
+    beta = beta.detach().clone().requires_grad_(True) if torch.is_tensor(beta) else float(beta)
+    bound = wl.scene.bound.to(dev)
+
+    def one():
+        t_rand = torch.rand(wl.R, wl.S, device=dev)
+        depth, color, sdf, z = orc.render_batch_ray(planes, params, beta, bound, wl.rays_d.detach(), wl.rays_o.detach(),
+                                                    wl.truncation, wl.gt_depth, wl.n_strat, wl.n_imp, t_rand, None, None)
+        orc.mapping_loss(depth, color, sdf, z, wl.gt_depth, wl.gt_color, wl.truncation).backward()
+        for grp in planes:
+            for p in grp:
+                p.grad = None
+    for _ in range(warmup):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        one()
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / iters
+    return {"value": wl.R * wl.S / t, "unit": "ray.samples/s", "ms_per_step": t * 1e3, "kind": "port",
+            "what": "oracle (PyTorch-op restatement of the reference path) with device='cuda' on the same MI355X, eager"}
 
 
 def main():
@@ -194,6 +229,14 @@ def main():
     if rank == 0:
         # reported on rank 0 at N=1 only (a host-side baseline does not change with the GPU count)
         out["cpu_baseline"] = cpu_baseline(wl) if (world == 1 and not args.no_cpu_baseline) else None
+        if out["cpu_baseline"] is not None:
+            # same baseline leg, second device: the port's PyTorch ops run on this GPU instead of the host cores
+            try:
+                g = torch_gpu_baseline(wl)
+                g["hip_path_speedup"] = out["value"] / g["value"]
+                out["cpu_baseline"]["same_port_on_this_gpu"] = g
+            except Exception as e:
+                out["cpu_baseline"]["same_port_on_this_gpu"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

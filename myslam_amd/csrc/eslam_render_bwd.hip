@@ -221,6 +221,14 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const eslam_decoders_t dec
                 ft[i] = fnext[0][i]; ft[4 + i] = fnext[1][i]; ft[8 + i] = fnext[2][i]; ft[12 + i] = fnext[3][i];
             }
             if (b + 1 < nblk) load_block(b + 1, fnext);
+            // the same rows again in the "feature on the lane" layout of the g_W1 contraction (B operand): requested
+            // here so that the L1/L2 latency is covered by the 28 MFMAs of the recompute instead of stalling them later
+            float4_t fbk[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int64_t pk = min(p0 + 16 * b + 4 * q + ks, N - 1);
+                fbk[ks] = *(const float4_t*)(feat + pk * 128 + d * 64 + 4 * r);
+            }
             float4_t h1, h2;
             mlp_hidden(f, ft, h1, h2);
 
@@ -280,10 +288,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const eslam_decoders_t dec
             // g_W1[j][f]: B = features of point 4q+ks, columns permuted: column c of n-block nb <-> feature 4c + nb
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const int64_t pk = min(p0 + 16 * b + 4 * q + ks, N - 1);
-                const float4_t fb = *(const float4_t*)(feat + pk * 128 + d * 64 + 4 * r);
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb) gW1[nb] = mfma16(az1[ks], fb[nb], gW1[nb]);
+                for (int nb = 0; nb < 4; ++nb) gW1[nb] = mfma16(az1[ks], fbk[ks][nb], gW1[nb]);
             }
             WAVE_SYNC();
         }

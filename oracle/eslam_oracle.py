@@ -103,8 +103,8 @@ def depth_guided_z(gt_depth, n_stratified, n_importance, truncation, t_rand=None
     """
     dt = gt_depth.dtype
     d = gt_depth.reshape(-1, 1)
-    t_free = torch.linspace(0.0, 1.0, n_stratified, dtype=dt)
-    t_surf = torch.linspace(0.0, 1.0, n_importance, dtype=dt)
+    t_free = torch.linspace(0.0, 1.0, n_stratified, dtype=dt, device=gt_depth.device)
+    t_surf = torch.linspace(0.0, 1.0, n_importance, dtype=dt, device=gt_depth.device)
     z_surf = d - (1.5 * truncation) + (3 * truncation * t_surf)           # Renderer.py:97
     z_free = 0.0 + 1.2 * d * t_free                                       # Renderer.py:100
     z = torch.sort(torch.cat([z_free, z_surf], -1), -1).values            # Renderer.py:102
@@ -162,14 +162,28 @@ def bilinear_border(plane, gx, gy):
     return (t00 * (1 - tx) * (1 - ty) + t01 * tx * (1 - ty) + t10 * (1 - tx) * ty + t11 * tx * ty)
 
 
+# "index": explicit index arithmetic (independent of ATen's grid_sampler; what the parity tests use).
+# "grid_sample": the torch op the reference itself calls (decoders.py:79-81) - same numbers (tests/test_oracle_golden.py
+# checks both against the fixtures), used for the timed baselines in bench.py because it is what the reference would run.
+BILINEAR_IMPL = "index"
+
+
+def _bilinear(plane, gx, gy):
+    if BILINEAR_IMPL == "grid_sample":
+        grid = torch.stack([gx, gy], -1)[None, :, None, :]
+        out = torch.nn.functional.grid_sample(plane, grid, padding_mode="border", align_corners=True, mode="bilinear")
+        return out[0, :, :, 0].t()
+    return bilinear_border(plane, gx, gy)
+
+
 def plane_features(p_nor, planes_xy, planes_xz, planes_yz):
     """Reference src/networks/decoders.py:64-85: per level sum the three orientations, concat levels."""
     x, y, z = p_nor[:, 0], p_nor[:, 1], p_nor[:, 2]
     feats = []
     for lvl in range(len(planes_xy)):
-        f = bilinear_border(planes_xy[lvl], x, y)
-        f = f + bilinear_border(planes_xz[lvl], x, z)
-        f = f + bilinear_border(planes_yz[lvl], y, z)
+        f = _bilinear(planes_xy[lvl], x, y)
+        f = f + _bilinear(planes_xz[lvl], x, z)
+        f = f + _bilinear(planes_yz[lvl], y, z)
         feats.append(f)
     return torch.cat(feats, -1)
 
@@ -249,7 +263,7 @@ def importance_z(rays_o, rays_d, all_planes, params, beta, bound, n_stratified, 
     with torch.no_grad():
         dt = rays_o.dtype
         far = aabb_exit(rays_o, rays_d, bound)[:, None] + 0.01           # Renderer.py:114-117
-        t = torch.linspace(0.0, 1.0, n_stratified, dtype=dt)
+        t = torch.linspace(0.0, 1.0, n_stratified, dtype=dt, device=rays_o.device)
         z_uni = 0.0 * (1.0 - t) + far * t                                 # Renderer.py:119
         if t_rand_uni is not None:
             z_uni = jitter(z_uni, t_rand_uni)
@@ -275,7 +289,7 @@ def sample_z(rays_o, rays_d, gt_depth, all_planes, params, beta, bound, truncati
     S = n_stratified + n_importance
     gt_depth = gt_depth.reshape(-1)
     has = gt_depth > 0
-    z = torch.empty(R, S, dtype=rays_o.dtype)
+    z = torch.empty(R, S, dtype=rays_o.dtype, device=rays_o.device)
     if has.any():
         z[has] = depth_guided_z(gt_depth[has], n_stratified, n_importance, truncation,
                                 None if t_rand is None else t_rand[has])
@@ -301,7 +315,7 @@ def render_batch_ray(all_planes, params, beta, bound, rays_d, rays_o, truncation
 
     Returns depth [R], rgb [R,3], sdf [R,S], z_vals [R,S].
     """
-    bound = bound.to(rays_o.dtype)
+    bound = bound.to(device=rays_o.device, dtype=rays_o.dtype)
     if z_vals is None:
         z_vals = sample_z(rays_o, rays_d, gt_depth, all_planes, params, beta, bound, truncation,
                           n_stratified, n_importance, t_rand, t_rand_uni, u)

@@ -317,3 +317,51 @@ def test_sharded_mapper_one_rank_rccl():
 def test_graft_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_matched_loss_over_adam_iterations():
+    """"At matched loss": 25 mapping iterations with Adam on the planes and decoders (the learning rates of
+    configs/ESLAM.yaml:58-61), HIP path on the GPU vs the oracle on the CPU, same rays and the same jitter numbers each
+    iteration.  The two loss curves must stay together - a check with the optimiser in the loop that no gradient is
+    subtly wrong (a wrong sign or scale would separate the curves within a few steps)."""
+    from oracle import eslam_oracle as orc
+    from myslam_amd import losses, synth
+    fx = hp.load("room0_200x32")
+    dev = _dev()
+    sc, planes, dec, renderer = build(fx)
+    ro = torch.from_numpy(fx["rays_o"]).to(dev)
+    rd = torch.from_numpy(fx["rays_d"]).to(dev)
+    gd = torch.from_numpy(fx["gt_depth"]).to(dev)
+    gc = torch.from_numpy(fx["gt_color"]).to(dev)
+    tr = float(fx["truncation"])
+    R, S = gd.shape[0], int(fx["n_stratified"]) + int(fx["n_importance"])
+    plist = hp.flat_planes(planes)
+    opt = torch.optim.Adam([{"params": list(dec.parameters()), "lr": 0.001}, {"params": plist[:6], "lr": 0.005},
+                            {"params": plist[6:], "lr": 0.005}])
+    # oracle twin on the CPU (NCHW planes, same values)
+    cplanes = tuple([torch.nn.Parameter(p.detach().cpu().contiguous()) for p in grp] for grp in planes)
+    cparams = {k: torch.nn.Parameter(v.detach().cpu().clone()) for k, v in dec.state_dict().items() if k != "beta"}
+    cbeta = torch.nn.Parameter(dec.beta.detach().cpu().clone())
+    cplist = hp.flat_planes(cplanes)
+    copt = torch.optim.Adam([{"params": list(cparams.values()) + [cbeta], "lr": 0.001},
+                             {"params": cplist[:6], "lr": 0.005}, {"params": cplist[6:], "lr": 0.005}])
+    hip_losses, ref_losses = [], []
+    for it in range(25):
+        t_rand = torch.from_numpy(synth.hash_uniform((R, S), 200_000 + it))
+        opt.zero_grad(set_to_none=True)
+        depth, color, sdf, z = renderer.render_batch_ray(planes, dec, rd, ro, dev, tr, gt_depth=gd,
+                                                         _rand=(t_rand.to(dev), None, None))
+        loss = losses.mapping_loss(depth, color, sdf, z, gd, gc, tr)
+        loss.backward()
+        opt.step()
+        hip_losses.append(float(loss))
+        copt.zero_grad(set_to_none=True)
+        cd, cc, cs, cz = orc.render_batch_ray(cplanes, cparams, cbeta, sc.bound, rd.cpu(), ro.cpu(), tr, gd.cpu(),
+                                              int(fx["n_stratified"]), int(fx["n_importance"]), t_rand, None, None)
+        closs = orc.mapping_loss(cd, cc, cs, cz, gd.cpu(), gc.cpu(), tr)
+        closs.backward()
+        copt.step()
+        ref_losses.append(float(closs))
+    hip_losses, ref_losses = np.array(hip_losses), np.array(ref_losses)
+    assert ref_losses[-1] < 0.8 * ref_losses[0], "the optimisation should make progress"
+    assert np.abs(hip_losses - ref_losses).max() <= 2e-3 * ref_losses[0], (hip_losses, ref_losses)

@@ -123,3 +123,17 @@ def test_oracle_float64_agrees_with_float32():
     assert hp.rel_err(r32["depth"].detach().numpy(), r64["depth"].detach().numpy()) <= 1e-5
     for k in r32["params"]:
         assert hp.rel_err(r32["params"][k].grad.numpy(), r64["params"][k].grad.numpy()) <= 1e-4
+
+
+def test_grid_sample_variant_of_the_oracle_matches_too(monkeypatch):
+    """bench.py times the oracle with F.grid_sample (what the reference calls); same function, same fixture."""
+    monkeypatch.setattr(orc, "BILINEAR_IMPL", "grid_sample")
+    fx = hp.load("room0_200x40_zero15")
+    r = run_oracle(fx)
+    pr = fx["probe"]
+    assert hp.rel_err(r["sdf"].detach().numpy()[pr], fx["sdf"]) <= OUT_RTOL
+    assert hp.rel_err(r["depth"].detach().numpy()[pr], fx["depth"]) <= OUT_RTOL
+    for k, p in r["params"].items():
+        assert hp.rel_err(p.grad.numpy(), fx["grad:" + k]) <= GRAD_RTOL, k
+    assert hp.rel_err(r["rd"].grad.numpy()[pr], fx["g_rays_d"]) <= GRAD_RTOL
+    hp.check_plane_probes(fx, [p.grad for p in hp.flat_planes(r["planes"])], rtol=GRAD_RTOL)
