@@ -202,10 +202,20 @@ def main():
     if rank == 0:
         prof = kernel_profile(wl.step, args.profile_iters)      # eager: the HIP events sit inside the C-ABI calls
         n = wl.R * wl.S
-        alg = {"render_fwd_kernel": BYTES_FWD * n, "scatter_kernel": BYTES_SCATTER * n}
+        alg = {"render_fwd_kernel": BYTES_FWD * n, "scatter_sort_kernel": BYTES_SCATTER * n}
         dom = max((k for k in prof if k in alg), key=lambda k: prof[k])
         achieved = alg[dom] / (prof[dom] * 1e-3) / 1e9
         other = [k for k in alg if k != dom][0]
+        # HBM-side traffic per launch comes from the separate rocprofv3 --pmc passes of this build (profiles/): counters
+        # cannot be read from inside this process
+        traffic, traffic_note = None, None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if dom in tj and wl.R * wl.S == 4096 * 64:
+                traffic = tj[dom]["traffic_bytes"]
+                traffic_note = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload)"
+        except Exception:
+            pass
         out = {
             "metric": "ray.samples/s (render+bwd)", "value": value, "unit": "ray.samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
@@ -216,7 +226,10 @@ def main():
                        "planes_layout": "channels_last", "parallelism": f"ray-sharded dp{world}",
                        "launch": "hipGraph replay of the captured iteration" if graphed else "eager launches from Python"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+                         "note": "the 27 MB of planes are L2 / Infinity-Cache resident and duplicate texel contributions are "
+                                 "merged on chip before they reach memory, so algorithmic bytes per second can exceed the HBM "
+                                 "peak; traffic is what the memory side actually saw",
                          "algorithmic_bytes_per_launch": alg[dom], "avg_kernel_ms": prof[dom],
                          "second_kernel": {"kernel": other, "avg_kernel_ms": prof.get(other),
                                            "achieved": alg[other] / (prof[other] * 1e-3) / 1e9 if other in prof else None},

@@ -69,7 +69,7 @@ static hipEvent_t g_ev[ESLAM_PROF_KERNELS][2];
 static bool g_ev_made = false;
 static bool g_ev_used[ESLAM_PROF_KERNELS];
 static const char* const g_prof_names[ESLAM_PROF_KERNELS] = {
-    "render_fwd_kernel", "composite_bwd_kernel", "mlp_bwd_kernel", "dec_grad_reduce_kernel", "scatter_kernel",
+    "render_fwd_kernel", "composite_bwd_kernel", "mlp_bwd_kernel", "dec_grad_reduce_kernel", "scatter_sort_kernel",
     "coord_bwd_kernel", "loss_reduce_kernel+loss_grad_kernel", "sample_z_kernel", "importance_z_kernel",
     "decode_fwd_kernel"};
 
