@@ -125,7 +125,8 @@ int64_t eslam_bwd_workspace_bytes(int64_t n_points);
 /* K8 backward of eslam_render_fwd (autograd of the lines above).
  * Upstream: g_depth [R], g_rgb [R,3], g_sdf [R,S] (any may be NULL = zero).
  * Accumulates into planes[i].grad (where non-NULL), OVERWRITES g_dec [ESLAM_N_DEC_PARAMS] (order of
- * eslam_decoders_t: w1,b1,w2,b2,w3,b3,cw1,...,cb3) and g_beta [1], and when g_rays_o / g_rays_d are
+ * eslam_decoders_t: w1,b1,w2,b2,w3,b3,cw1,...,cb3; NULL = decoders frozen, their gradient work is skipped) and
+ * g_beta [1] (may be NULL), and when g_rays_o / g_rays_d are
  * non-NULL overwrites them ([R,3] each) with the gradient through pts = o + d z.  z_vals carries no gradient
  * (Renderer.py builds it under no_grad / from gt_depth).  ray_order: the buffer eslam_render_fwd filled, or NULL
  * (then the order is computed here).  workspace: eslam_bwd_workspace_bytes(R*S) bytes.                      */

@@ -144,6 +144,9 @@ __global__ void decode_act_bwd_kernel(const float* __restrict__ raw, const float
 // decoder MLP backward (autograd of reference src/networks/decoders.py:97-103 / 117-123)
 // ---------------------------------------------------------------------------------------------------------
 #define TP 20                      // row pitch (floats) of the 16x16 transpose tiles: conflict-free, 16-B aligned
+// WGRAD = false: decoders are frozen (tracking, reference src/Tracker.py:111-112): only g_feat is produced, the
+// parameter-gradient contractions (28 of the 68 MFMAs per block), their LDS transposes and the slabs are skipped.
+template <bool WGRAD>
 __global__ __launch_bounds__(256) void mlp_bwd_kernel(const eslam_decoders_t dec, const float* __restrict__ feat,
                                                       const float* __restrict__ g_o, int64_t N,
                                                       float* __restrict__ g_feat, float* __restrict__ slabs) {
@@ -224,10 +227,12 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const eslam_decoders_t dec
             // the same rows again in the "feature on the lane" layout of the g_W1 contraction (B operand): requested
             // here so that the L1/L2 latency is covered by the 28 MFMAs of the recompute instead of stalling them later
             float4_t fbk[4];
+            if (WGRAD) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int64_t pk = min(p0 + 16 * b + 4 * q + ks, N - 1);
-                fbk[ks] = *(const float4_t*)(feat + pk * 128 + d * 64 + 4 * r);
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int64_t pk = min(p0 + 16 * b + 4 * q + ks, N - 1);
+                    fbk[ks] = *(const float4_t*)(feat + pk * 128 + d * 64 + 4 * r);
+                }
             }
             float4_t h1, h2;
             mlp_hidden(f, ft, h1, h2);
@@ -261,6 +266,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const eslam_decoders_t dec
                 for (int i = 0; i < 4; ++i) gf[(mb >> 1) * 8 + 4 * (mb & 1) + i] = acc[i];
             }
             if (p0 + 16 * b + r < N) store_features(g_feat, p0 + 16 * b + r, d, q, gf);
+            if (!WGRAD) continue;
 
             // transposes through LDS: D layout (rows 4q+reg, col = point r) -> [point][row]
             *(float4_t*)(tz1 + r * TP + 4 * q) = gz1;
@@ -295,6 +301,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const eslam_decoders_t dec
         }
     }
 
+    if (!WGRAD) return;
     // per-wave slab: [wave_global][decoder] -> SLAB floats
     float* sl = slabs + (((int64_t)blockIdx.x * 4 + wave) * 2 + d) * SLAB;
 #pragma unroll
@@ -328,6 +335,20 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const eslam_decoders_t dec
     }
 }
 
+__global__ __launch_bounds__(1024) void beta_sum_kernel(const float* __restrict__ parts, int n, float* __restrict__ out) {
+    __shared__ float bsum[16];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) a += parts[i];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) bsum[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int k = 0; k < 16; ++k) t += bsum[k];
+        out[0] = t;
+    }
+}
+
 // slabs [nrows][2][SLAB] -> g_dec (flat, order of eslam_decoders_t).  grid (ceil(SLAB/64), 2), block 1024 =
 // 64 columns x 16 row groups; every thread keeps 8 independent loads in flight (the first version walked 512 rows
 // with one load outstanding and took 0.19 ms for 22 MB).
@@ -337,7 +358,7 @@ __global__ __launch_bounds__(1024) void dec_grad_reduce_kernel(const float* __re
                                                                const float* __restrict__ beta_parts, int n_beta_parts,
                                                                float* __restrict__ g_beta) {
     __shared__ float red[RED_PARTS][64];
-    if (blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && beta_parts) {
+    if (blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && beta_parts && g_beta) {
         // the last column block has only 20 live columns: it also sums the g_beta partials
         __shared__ float bsum[16];
         float a = 0.f;
@@ -518,7 +539,7 @@ __device__ __forceinline__ void coord_grad8(const eslam_plane_t& P, float u, flo
 }
 
 template <bool CL, bool RENDER>
-__global__ __launch_bounds__(256, 4) void coord_bwd_kernel(const PlaneSet planes, const Bound bnd,
+__global__ __launch_bounds__(256, 2) void coord_bwd_kernel(const PlaneSet planes, const Bound bnd,
                                                         const float* __restrict__ rays_o,
                                                         const float* __restrict__ rays_d,
                                                         const float* __restrict__ z_vals, int R, int S,
@@ -540,7 +561,9 @@ __global__ __launch_bounds__(256, 4) void coord_bwd_kernel(const PlaneSet planes
     const int scount = RENDER ? S : (int)min((int64_t)64, (int64_t)R - base);
     const float sc3[3] = {2.0f / (bnd.hi[0] - bnd.lo[0]), 2.0f / (bnd.hi[1] - bnd.lo[1]), 2.0f / (bnd.hi[2] - bnd.lo[2])};
     float go_acc[3] = {0.f, 0.f, 0.f}, gd_acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll 1
     for (int s0 = 0; s0 < scount; s0 += 16) {
+        const int oz0 = opaque_zero(s0);      // keeps the 12 planes' scalar loads inside this loop (see gather_features)
         const int s = s0 + r;
         const bool valid = s < scount;
         const int sc_ = min(s, scount - 1);
@@ -564,7 +587,7 @@ __global__ __launch_bounds__(256, 4) void coord_bwd_kernel(const PlaneSet planes
                 const float g[8] = {ga[0], ga[1], ga[2], ga[3], gb[0], gb[1], gb[2], gb[3]};
 #pragma unroll
                 for (int o = 0; o < 3; ++o) {
-                    const eslam_plane_t& P = planes.p[2 * (3 * d + o) + lvl];
+                    const eslam_plane_t& P = planes.p[2 * (3 * d + o) + lvl + oz0];
                     float gu = 0.f, gv = 0.f;
                     coord_grad8<CL>(P, ORIENT_U(o, x, y, z), ORIENT_V(o, x, y, z), q, g, gu, gv);
                     __builtin_amdgcn_sched_barrier(0);
@@ -670,13 +693,18 @@ static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, 
     const int64_t ntiles = (N + 63) / 64;
     const int nwg = (int)((ntiles + 3) / 4 < MLP_BWD_MAX_WG ? (ntiles + 3) / 4 : MLP_BWD_MAX_WG);
     eslam_prof_begin(PROF_MLP_BWD, st);
-    hipLaunchKernelGGL(mlp_bwd_kernel, dim3(nwg, 2), dim3(256), 0, st, *dec, feat, g_o, N, g_feat, slabs);
+    if (g_dec)
+        hipLaunchKernelGGL(mlp_bwd_kernel<true>, dim3(nwg, 2), dim3(256), 0, st, *dec, feat, g_o, N, g_feat, slabs);
+    else
+        hipLaunchKernelGGL(mlp_bwd_kernel<false>, dim3(nwg, 2), dim3(256), 0, st, *dec, feat, g_o, N, g_feat, slabs);
     eslam_prof_end(PROF_MLP_BWD, st);
     if (int rc = eslam_check_launch("mlp_bwd_kernel")) return rc;
+    AuxStream* aux = nullptr;
+    if (g_dec) {
     // The slab reduction (44 workgroups, latency-bound, ~16 us) does not depend on the scatter and the scatter does not
     // depend on it: fork it onto the library's auxiliary stream and join at the end of the call (event fork/join, which
     // a hipGraph capture of the caller's stream follows).
-    AuxStream* aux = aux_stream();
+    aux = aux_stream();
     hipStream_t rs = st;
     if (aux) {
         if (hipEventRecord(aux->fork, st) != hipSuccess || hipStreamWaitEvent(aux->stream, aux->fork, 0) != hipSuccess) {
@@ -693,6 +721,13 @@ static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, 
     if (aux && hipEventRecord(aux->join, rs) != hipSuccess) {
         eslam_set_error("eslam_render_bwd: stream join record failed");
         return 2;
+    }
+    } else {
+        aux = nullptr;
+        if (g_beta) {      // beta's gradient does not go through the decoders: still sum its partials
+            hipLaunchKernelGGL(beta_sum_kernel, dim3(1), dim3(1024), 0, st, beta_parts, n_beta_parts, g_beta);
+            if (int rc = eslam_check_launch("beta_sum_kernel")) return rc;
+        }
     }
 
     // plane gradients
@@ -754,8 +789,7 @@ extern "C" int eslam_render_bwd(const eslam_plane_t* planes, const eslam_decoder
         eslam_set_error("eslam_render_bwd: S=%d outside [1,%d]", S, ESLAM_MAX_SAMPLES);
         return 1;
     }
-    if (!planes || !dec || !bound6_host || !rays_o || !rays_d || !z_vals || !sdf || !raw_rgb || !feat || !g_dec ||
-        !g_beta || !workspace) {
+    if (!planes || !dec || !bound6_host || !rays_o || !rays_d || !z_vals || !sdf || !raw_rgb || !feat || !workspace) {
         eslam_set_error("eslam_render_bwd: null argument");
         return 1;
     }
@@ -798,7 +832,7 @@ extern "C" int eslam_decode_bwd(const eslam_plane_t* planes, const eslam_decoder
                                 const float* pts, int64_t N, const float* raw, const float* feat, const float* g_raw,
                                 float* g_dec, float* g_pts, void* workspace, eslam_stream_t stream) {
     if (N <= 0) return 0;
-    if (!planes || !dec || !bound6_host || !pts || !raw || !feat || !g_raw || !g_dec || !workspace) {
+    if (!planes || !dec || !bound6_host || !pts || !raw || !feat || !g_raw || !workspace) {
         eslam_set_error("eslam_decode_bwd: null argument");
         return 1;
     }

@@ -191,8 +191,9 @@ class RenderFn(torch.autograd.Function):
             g_beta = sink.flat[sink.offsets[24]:sink.offsets[24] + 1] if len(sink.views) > 24 else \
                 torch.empty(1, device=dev)
         else:
-            g_dec = torch.empty(_hip.N_DEC_PARAMS, device=dev)
-            g_beta = torch.empty(1, device=dev)
+            need_dec = any(need[18:30])
+            g_dec = torch.empty(_hip.N_DEC_PARAMS, device=dev) if need_dec else None
+            g_beta = torch.empty(1, device=dev) if need[4] else None
         g_ro = torch.empty(R, 3, device=dev) if need_rays else None
         g_rd = torch.empty(R, 3, device=dev) if need_rays else None
         ws = torch.empty(lib.eslam_bwd_workspace_bytes(R * S), dtype=torch.uint8, device=dev)
@@ -207,7 +208,7 @@ class RenderFn(torch.autograd.Function):
         if sink is not None:
             # the data-parallel caller owns .grad assignment (FlatGrads.assign): hand autograd nothing to accumulate
             return (g_ro if need[0] else None, g_rd if need[1] else None) + (None,) * 28
-        dec_grads = _split_dec_grads(g_dec)
+        dec_grads = _split_dec_grads(g_dec) if g_dec is not None else [None] * 12
         out = [g_ro if need[0] else None, g_rd if need[1] else None, None, None, g_beta if need[4] else None, None]
         out += [grads[i] if (need_planes and need[6 + i]) else None for i in range(12)]
         out += [dec_grads[i] if need[18 + i] else None for i in range(12)]
