@@ -160,7 +160,7 @@ int eslam_decode_bwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, c
  * Means over empty sets give NaN exactly as torch.mean does.  scratch: 64 bytes, any contents.            */
 int eslam_mapping_loss(const float* depth, const float* rgb, const float* sdf, const float* z_vals,
                        const float* gt_depth, const float* gt_color, int R, int S, double truncation,
-                       const float* weights5_host, int unused_flags, const uint8_t* ray_mask, float* loss,
+                       const float* weights5_host, const uint8_t* ray_mask, float* loss,
                        float* g_depth, float* g_rgb, float* g_sdf, void* scratch, eslam_stream_t stream);
 
 /* The two phases of eslam_mapping_loss separately, for ray-sharded data parallelism: every rank runs

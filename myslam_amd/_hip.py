@@ -52,7 +52,7 @@ SIGNATURES = {
                               _vp, _vp, _vp]),
     "eslam_decode_fwd": (_i, [_PP, _DP, _BP, _vp, _i64, _i, _vp, _vp, _vp]),
     "eslam_decode_bwd": (_i, [_PP, _DP, _BP, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "eslam_mapping_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _BP, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "eslam_mapping_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _BP, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "eslam_loss_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp]),
     "eslam_profile_enable": (_i, [_i]),
     "eslam_profile_read": (_i, [_BP]),

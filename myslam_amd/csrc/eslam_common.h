@@ -16,7 +16,6 @@ struct PlaneSet {
 
 struct Bound {
     float lo[3];
-    float inv_len_unused[3];   // kept for layout stability
     float hi[3];
 };
 

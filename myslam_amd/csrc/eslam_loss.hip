@@ -156,9 +156,8 @@ extern "C" int eslam_loss_grad(const float* depth, const float* rgb, const float
 
 extern "C" int eslam_mapping_loss(const float* depth, const float* rgb, const float* sdf, const float* z_vals,
                                   const float* gt_depth, const float* gt_color, int R, int S, double truncation,
-                                  const float* weights5_host, int unused_flags, const uint8_t* ray_mask, float* loss,
+                                  const float* weights5_host, const uint8_t* ray_mask, float* loss,
                                   float* g_depth, float* g_rgb, float* g_sdf, void* scratch, eslam_stream_t stream) {
-    (void)unused_flags;
     if (!scratch) {
         eslam_set_error("eslam_mapping_loss: null scratch");
         return 1;

@@ -4,9 +4,7 @@
 //   mlp_bwd_kernel         per 64-point tile and decoder: recompute hidden layers, back-propagate to the 64
 //                          features (g_feat[N,128]) and to the decoder parameters (per-wave slabs); fp32 MFMA
 //   dec_grad_reduce_kernel slabs -> flat decoder gradient
-//   scatter_kernel         g_feat -> plane gradients: per ray and (decoder, level) one wave walks the samples in
-//                          order, merges consecutive samples that fall into the same texel cell in registers and
-//                          flushes 256-B-shaped float atomics (2 texels x 32 channels per wave instruction)
+//   scatter (eslam_scatter.hip)  g_feat -> plane gradients
 //   coord_bwd_kernel       optional: gradient w.r.t. the sample position -> rays_o / rays_d (pose) or points
 #include <stdlib.h>
 #include "eslam_decode_tile.h"
@@ -403,103 +401,6 @@ __global__ __launch_bounds__(1024) void dec_grad_reduce_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// scatter of feature gradients into the plane gradients (autograd of decoders.py:79-82, i.e. of the 12 grid_sample)
-// ---------------------------------------------------------------------------------------------------------
-// One wave = one ray x one (decoder, level): the three orientations of that level share the 32 gradient channels.
-// Lane (hx = l >> 5, c = l & 31): hx selects the x-corner (x0 / x1), c the channel.  Samples are visited in z
-// order; while consecutive samples stay in the same bilinear cell of a plane their contributions are summed in two
-// registers (row y0, row y1) and written with one pair of atomic instructions when the cell changes.
-template <bool RENDER>
-__global__ __launch_bounds__(256) void scatter_kernel(const PlaneSet planes, const Bound bnd,
-                                                      const float* __restrict__ rays_o,
-                                                      const float* __restrict__ rays_d,
-                                                      const float* __restrict__ z_vals,   // RENDER: [R,S]; else pts [N,3]
-                                                      int R, int S, const float* __restrict__ g_feat) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ray = blockIdx.x;
-    const int d = wave >> 1, lvl = wave & 1;
-    const int hx = lane >> 5, c = lane & 31;
-    float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
-    if (RENDER) {
-        ox = rays_o[ray * 3 + 0]; oy = rays_o[ray * 3 + 1]; oz = rays_o[ray * 3 + 2];
-        dx = rays_d[ray * 3 + 0]; dy = rays_d[ray * 3 + 1]; dz = rays_d[ray * 3 + 2];
-    }
-    const int64_t base = (int64_t)ray * S;
-    const int64_t npts = RENDER ? (int64_t)R * S : (int64_t)R;     // decode mode: R = N points, S = 64 per "ray"
-    const int scount = RENDER ? S : (int)min((int64_t)S, npts - base);
-
-    // run state per orientation
-    int cur0[3], cur1[3], curdx[3];
-    float acc0[3], acc1[3];
-#pragma unroll
-    for (int o = 0; o < 3; ++o) { cur0[o] = -1; cur1[o] = -1; curdx[o] = 0; acc0[o] = 0.f; acc1[o] = 0.f; }
-
-    for (int c0 = 0; c0 < scount; c0 += WAVE) {
-        const int nvalid = min(WAVE, scount - c0);
-        // sample role: cell coordinates of point c0 + lane in the three planes of this (decoder, level)
-        float x, y, z;
-        {
-            const int s = min(c0 + lane, scount - 1);
-            if (RENDER) {
-                const float zz = z_vals[base + s];
-                x = ox + dx * zz; y = oy + dy * zz; z = oz + dz * zz;
-            } else {
-                x = z_vals[(base + s) * 3 + 0]; y = z_vals[(base + s) * 3 + 1]; z = z_vals[(base + s) * 3 + 2];
-            }
-            x = norm_coord(x, bnd.lo[0], bnd.hi[0]);
-            y = norm_coord(y, bnd.lo[1], bnd.hi[1]);
-            z = norm_coord(z, bnd.lo[2], bnd.hi[2]);
-        }
-        int off0[3], off1[3], offdx[3];
-        float tx[3], ty[3];
-#pragma unroll
-        for (int o = 0; o < 3; ++o) {
-            const eslam_plane_t& P = planes.p[2 * (3 * d + o) + lvl];
-            const AxisCoord ax = axis_coord(ORIENT_U(o, x, y, z), P.w);
-            const AxisCoord ay = axis_coord(ORIENT_V(o, x, y, z), P.h);
-            off0[o] = ay.i0 * (int)P.stride_y + ax.i0 * (int)P.stride_x;
-            off1[o] = ay.i1 * (int)P.stride_y + ax.i0 * (int)P.stride_x;
-            offdx[o] = (ax.i1 - ax.i0) * (int)P.stride_x;
-            tx[o] = ax.t;
-            ty[o] = ay.t;
-        }
-        for (int i = 0; i < nvalid; ++i) {
-            const float g = g_feat[(base + c0 + i) * 128 + d * 64 + lvl * 32 + c];
-#pragma unroll
-            for (int o = 0; o < 3; ++o) {
-                const eslam_plane_t& P = planes.p[2 * (3 * d + o) + lvl];
-                const int n0 = __builtin_amdgcn_readlane(off0[o], i);
-                const int n1 = __builtin_amdgcn_readlane(off1[o], i);
-                const int ndx = __builtin_amdgcn_readlane(offdx[o], i);
-                const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tx[o]), i));
-                const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ty[o]), i));
-                if (n0 != cur0[o] || n1 != cur1[o] || ndx != curdx[o]) {     // wave-uniform
-                    if (cur0[o] >= 0) {
-                        float* gp = P.grad + hx * curdx[o] + c * (int)P.stride_c;
-                        atomicAdd(gp + cur0[o], acc0[o]);
-                        atomicAdd(gp + cur1[o], acc1[o]);
-                    }
-                    cur0[o] = n0; cur1[o] = n1; curdx[o] = ndx;
-                    acc0[o] = 0.f; acc1[o] = 0.f;
-                }
-                const float wx = hx ? sx : 1.0f - sx;
-                acc0[o] += g * (wx * (1.0f - sy));
-                acc1[o] += g * (wx * sy);
-            }
-        }
-    }
-#pragma unroll
-    for (int o = 0; o < 3; ++o) {
-        if (cur0[o] >= 0) {
-            const eslam_plane_t& P = planes.p[2 * (3 * d + o) + lvl];
-            float* gp = P.grad + hx * curdx[o] + c * (int)P.stride_c;
-            atomicAdd(gp + cur0[o], acc0[o]);
-            atomicAdd(gp + cur1[o], acc1[o]);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // gradient w.r.t. sample positions (autograd of the grid coordinates + common.py:215-217 + Renderer.py:136-137)
 // ---------------------------------------------------------------------------------------------------------
 template <bool CL>
@@ -633,7 +534,6 @@ static Bound make_bound(const float* b6) {
     for (int k = 0; k < 3; ++k) {
         b.lo[k] = b6[2 * k];
         b.hi[k] = b6[2 * k + 1];
-        b.inv_len_unused[k] = 0.f;
     }
     return b;
 }
@@ -740,21 +640,10 @@ static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, 
         eslam_set_error("plane gradients must be requested for all 12 planes or for none");
         return 1;
     }
-    static const bool use_v1 = getenv("ESLAM_SCATTER_V1") != nullptr;     // A/B switch for profiling only
-    if (any_grad && !use_v1) {
+    if (any_grad) {
         eslam_prof_begin(PROF_SCATTER, st);
         if (int rc = eslam_scatter_v2(planes, bnd, rays_o, rays_d, z_or_pts, R, S, render, g_feat, perm, st)) return rc;
         eslam_prof_end(PROF_SCATTER, st);
-    } else if (any_grad) {
-        eslam_prof_begin(PROF_SCATTER, st);
-        if (render)
-            hipLaunchKernelGGL((scatter_kernel<true>), dim3((unsigned)R), dim3(256), 0, st, ps, bnd, rays_o, rays_d,
-                               z_or_pts, (int)R, S, g_feat);
-        else
-            hipLaunchKernelGGL((scatter_kernel<false>), dim3((unsigned)ntiles), dim3(256), 0, st, ps, bnd, rays_o,
-                               rays_d, z_or_pts, (int)R, 64, g_feat);
-        eslam_prof_end(PROF_SCATTER, st);
-        if (int rc = eslam_check_launch("scatter_kernel")) return rc;
     }
     // position gradients
     if (g_out_a) {

@@ -182,7 +182,6 @@ static Bound make_bound(const float* b6) {
     for (int k = 0; k < 3; ++k) {
         b.lo[k] = b6[2 * k];
         b.hi[k] = b6[2 * k + 1];
-        b.inv_len_unused[k] = 0.f;
     }
     return b;
 }
