@@ -135,6 +135,22 @@ def torch_gpu_baseline(wl, iters=10, warmup=3):
 
 
 def main():
+    # stdout carries exactly one JSON line.  Native libraries print there too (RCCL writes a version banner when its first
+    # communicator is created), so the process-level fd 1 points at stderr until the line is ready.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        line = run()
+    finally:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
+    if line is not None:
+        print(line, flush=True)
+
+
+def run():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -155,18 +171,25 @@ def main():
 
     from myslam_amd import harness
     wl = harness.make_workload(SCENE, RAYS, N_STRAT, N_IMP, device=dev, seed=rank)
-    if world > 1:
+    mapper = None
+    if world > 1 or os.environ.get("BENCH_FORCE_DP") == "1":      # BENCH_FORCE_DP: exercise the sharded step on one rank
         from myslam_amd.parallel import ShardedMapper
+        if world == 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         mapper = ShardedMapper(wl)
         step = mapper.step
     else:
         step = wl.step
     eager_step = step
     graphed = False
-    if world == 1 and not args.no_graph:
-        # capture the iteration into a hipGraph: the step is launch-bound when issued from Python
+    if not args.no_graph and (world == 1 or os.environ.get("BENCH_DP_GRAPH", "1") == "1"):
+        # capture the iteration into a hipGraph: the step is launch-bound when issued from Python.  With N > 1 the two
+        # RCCL all-reduces of the step are captured with it (BENCH_DP_GRAPH=0 keeps the sharded step eager).
         try:
-            step = harness.GraphedStep(wl.step, wl.params())
+            step = harness.GraphedStep(eager_step, mapper.params if mapper is not None else wl.params())
             graphed = True
         except Exception as e:       # report, never hide: the JSON line says which mode was timed
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
@@ -239,6 +262,7 @@ def main():
         }
     if world > 1:
         dist.barrier()
+    line = None
     if rank == 0:
         # reported on rank 0 at N=1 only (a host-side baseline does not change with the GPU count)
         out["cpu_baseline"] = cpu_baseline(wl) if (world == 1 and not args.no_cpu_baseline) else None
@@ -250,10 +274,14 @@ def main():
                 out["cpu_baseline"]["same_port_on_this_gpu"] = g
             except Exception as e:
                 out["cpu_baseline"]["same_port_on_this_gpu"] = {"error": f"{type(e).__name__}: {e}"}
-        print(json.dumps(out))
+        line = json.dumps(out)
     if world > 1:
         dist.barrier()
-        dist.destroy_process_group()
+    if world > 1 or mapper is not None:
+        import torch.distributed as dist2
+        if dist2.is_initialized():
+            dist2.destroy_process_group()
+    return line
 
 
 if __name__ == "__main__":

@@ -123,7 +123,8 @@ class GraphedStep:
         for p in self.params:
             p.grad = None
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: other threads (e.g. the RCCL watchdog of a process group) may touch the runtime while we capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss = step_fn()
         torch.cuda.synchronize()
 
