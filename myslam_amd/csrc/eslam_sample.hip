@@ -420,11 +420,11 @@ extern "C" int eslam_importance_z(const eslam_plane_t* planes, const eslam_decod
                                   int n_imp, const float* t_free, const float* t_rand_uni, const float* u,
                                   float* z_vals, eslam_stream_t stream) {
     if (R <= 0) return 0;
-    if (n_strat < 3 || n_imp < 1 || n_strat + n_imp > ESLAM_MAX_SAMPLES) {
+    if (n_strat < 3 || n_imp < 0 || n_strat + n_imp > ESLAM_MAX_SAMPLES) {
         eslam_set_error("eslam_importance_z: n_strat=%d n_imp=%d unsupported", n_strat, n_imp);
         return 1;
     }
-    if (!planes || !dec || !bound6_host || !rays_o || !rays_d || !gt_depth || !t_free || !u || !z_vals) {
+    if (!planes || !dec || !bound6_host || !rays_o || !rays_d || !gt_depth || !t_free || (n_imp > 0 && !u) || !z_vals) {
         eslam_set_error("eslam_importance_z: null argument");
         return 1;
     }
