@@ -185,11 +185,14 @@ def run():
         step = wl.step
     eager_step = step
     graphed = False
-    if not args.no_graph and (world == 1 or os.environ.get("BENCH_DP_GRAPH", "1") == "1"):
-        # capture the iteration into a hipGraph: the step is launch-bound when issued from Python.  With N > 1 the two
-        # RCCL all-reduces of the step are captured with it (BENCH_DP_GRAPH=0 keeps the sharded step eager).
+    if not args.no_graph:
+        # capture the iteration into hipGraphs: the step is launch-bound when issued from Python.  With N > 1 the two
+        # collective-free phases of the sharded step are captured separately and the two RCCL all-reduces stay eager.
         try:
-            step = harness.GraphedStep(eager_step, mapper.params if mapper is not None else wl.params())
+            if mapper is not None:
+                mapper.capture()
+            else:
+                step = harness.GraphedStep(eager_step, wl.params())
             graphed = True
         except Exception as e:       # report, never hide: the JSON line says which mode was timed
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
@@ -247,7 +250,9 @@ def run():
                                    "mapping iteration: sample + render fwd + loss + bwd (planes+decoders), no optimiser",
                        "rays_after_aabb_filter": wl.R, "samples_per_ray": wl.S, "plane_bytes": wl.scene.plane_bytes,
                        "planes_layout": "channels_last", "parallelism": f"ray-sharded dp{world}",
-                       "launch": "hipGraph replay of the captured iteration" if graphed else "eager launches from Python"},
+                       "launch": ("hipGraph replay of the captured iteration" + (" (2 graphs, all-reduces eager)" if mapper is not None
+                                                                                              else ""))
+                       if graphed else "eager launches from Python"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "note": "the 27 MB of planes are L2 / Infinity-Cache resident and duplicate texel contributions are "

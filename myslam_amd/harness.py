@@ -17,20 +17,22 @@ from .src.utils.Renderer import Renderer
 
 class Workload:
     def __init__(self, scene_name, R, n_strat, n_imp, device, zero_frac=0.0, seed=0, channels_last=True,
-                 rays_grad=False, planes="normal"):
+                 rays_grad=False, planes="normal", model_seed=0):
+        """seed: image / pixel choice of this rank's rays; model_seed: planes and decoders (same on every rank of a
+        data-parallel job, whose replicas must be identical)."""
         dev = torch.device(device)
         self.device = dev
         sc = scn.make_scene(scene_name)
         self.scene = sc
         self.truncation = sc.truncation
         gen = torch.Generator(device=dev)
-        gen.manual_seed(seed)
+        gen.manual_seed(model_seed)
         if planes == "normal":
             pl = scn.random_planes(sc, dev, generator=gen, channels_last=channels_last)
         else:
             pl = scn.synth_planes(sc, device=dev, channels_last=channels_last)
         self.planes = tuple([torch.nn.Parameter(p) for p in grp] for grp in pl)      # as Mapper.py:254-266
-        torch.manual_seed(seed)
+        torch.manual_seed(model_seed)
         self.decoders = Decoders(learnable_beta=sc.learnable_beta).to(dev)
         self.decoders.bound = sc.bound
         cfg = sc.cfg(perturb=True)

@@ -14,11 +14,11 @@ TRACKING_W = (10.0, 200.0, 50.0, 1.0, 5.0)
 
 def mapping_loss(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights=MAPPING_W):
     """Mapper.py:337-346: SDF + depth terms over rays with gt_depth > 0, colour over all rays."""
-    return ops.MappingLossFn.apply(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights, None, None)
+    return ops.MappingLossFn.apply(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights, None, None, None)
 
 
 def tracking_loss(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights=TRACKING_W):
     """Tracker.py:192-204: all terms over the rays whose depth error is below 10x the median error."""
     err = (gt_depth - depth.detach()).abs()
     mask = err < 10 * err.median()
-    return ops.MappingLossFn.apply(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights, mask, None)
+    return ops.MappingLossFn.apply(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights, mask, None, None)

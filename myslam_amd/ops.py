@@ -393,39 +393,52 @@ def sample_z(rays_o, rays_d, gt_depth, all_planes, decoders, bound6, truncation,
     return z
 
 
+def loss_reduce(depth, rgb, sdf, z_vals, gt_depth, gt_color, truncation, ray_mask=None, acc=None):
+    """Phase 1 of the fused loss (eslam_loss_reduce): set sizes and squared-error sums of this rank's rays accumulated
+    into acc [16] (zeroed here unless given)."""
+    for n, t in (("depth", depth), ("rgb", rgb), ("sdf", sdf), ("z_vals", z_vals), ("gt_depth", gt_depth),
+                 ("gt_color", gt_color)):
+        _hip.require_gpu_f32(n, t)
+    dev = depth.device
+    R, S = sdf.shape
+    args = [_c(t.detach()) for t in (depth, rgb, sdf, z_vals, gt_depth, gt_color)]
+    if acc is None:
+        acc = torch.zeros(16, device=dev)
+    else:
+        acc.zero_()
+    with torch.cuda.device(dev):
+        _hip.check(_hip.lib().eslam_loss_reduce(*[_hip.ptr(t) for t in args], R, S, float(truncation), _hip.ptr(ray_mask),
+                                                _hip.ptr(acc), _hip.stream_handle(dev)), "eslam_loss_reduce")
+    return acc
+
+
 class MappingLossFn(torch.autograd.Function):
-    """loss = MappingLossFn.apply(depth, rgb, sdf, z_vals, gt_depth, gt_color, truncation, weights5, ray_mask, group)
+    """loss = MappingLossFn.apply(depth, rgb, sdf, z_vals, gt_depth, gt_color, truncation, weights5, ray_mask, group, acc)
 
     Fused restatement of Mapper.py:110-144,337-346 (ray_mask None) / Tracker.py:114-148,197-204 (ray_mask given).
     forward = eslam_loss_reduce (+ the loss value); backward = eslam_loss_grad scaled by the upstream gradient inside the
     kernel.  `group`: a torch.distributed process group (or True for the default group) makes the set sizes and error
-    sums global with one 16-float all-reduce, for ray-sharded data parallelism (myslam_amd/parallel.py)."""
+    sums global with one 16-float all-reduce, for ray-sharded data parallelism (myslam_amd/parallel.py).
+    `acc`: accumulators that are already reduced (loss_reduce + the caller's own all-reduce); skips phase 1."""
 
     @staticmethod
-    def forward(ctx, depth, rgb, sdf, z_vals, gt_depth, gt_color, truncation, weights5, ray_mask, group=None):
-        for n, t in (("depth", depth), ("rgb", rgb), ("sdf", sdf), ("z_vals", z_vals), ("gt_depth", gt_depth),
-                     ("gt_color", gt_color)):
-            _hip.require_gpu_f32(n, t)
+    def forward(ctx, depth, rgb, sdf, z_vals, gt_depth, gt_color, truncation, weights5, ray_mask, group, acc):
+        if ray_mask is not None:
+            ray_mask = _c(ray_mask.to(torch.uint8))
+        if acc is None:
+            acc = loss_reduce(depth, rgb, sdf, z_vals, gt_depth, gt_color, truncation, ray_mask)
+            if group is not None:
+                import torch.distributed as dist
+                dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=None if group is True else group)
         dev = depth.device
         R, S = sdf.shape
         args = [_c(t.detach()) for t in (depth, rgb, sdf, z_vals, gt_depth, gt_color)]
-        if ray_mask is not None:
-            ray_mask = _c(ray_mask.to(torch.uint8))
         loss = torch.empty(1, device=dev)
-        acc = torch.zeros(16, device=dev)
         w = (ctypes.c_float * 5)(*[float(v) for v in weights5])
-        ptrs = [_hip.ptr(t) for t in args]
-        lib = _hip.lib()
         with torch.cuda.device(dev):
-            _hip.check(lib.eslam_loss_reduce(*ptrs, R, S, float(truncation), _hip.ptr(ray_mask), _hip.ptr(acc),
-                                             _hip.stream_handle(dev)), "eslam_loss_reduce")
-        if group is not None:
-            import torch.distributed as dist
-            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=None if group is True else group)
-        with torch.cuda.device(dev):
-            _hip.check(lib.eslam_loss_grad(*ptrs, R, S, float(truncation), w, _hip.ptr(ray_mask), _hip.ptr(acc),
-                                           _hip.ptr(loss), None, None, None, None, _hip.stream_handle(dev)),
-                       "eslam_loss_grad(value)")
+            _hip.check(_hip.lib().eslam_loss_grad(*[_hip.ptr(t) for t in args], R, S, float(truncation), w,
+                                                  _hip.ptr(ray_mask), _hip.ptr(acc), _hip.ptr(loss), None, None, None,
+                                                  None, _hip.stream_handle(dev)), "eslam_loss_grad(value)")
         ctx.save_for_backward(*args, acc)
         ctx.ray_mask = ray_mask
         ctx.consts = (float(truncation), tuple(float(v) for v in weights5))
@@ -447,4 +460,4 @@ class MappingLossFn(torch.autograd.Function):
                                                   _hip.ptr(ctx.ray_mask), _hip.ptr(acc), None, _hip.ptr(g_depth),
                                                   _hip.ptr(g_rgb), _hip.ptr(g_sdf), _hip.ptr(g),
                                                   _hip.stream_handle(dev)), "eslam_loss_grad")
-        return g_depth, g_rgb, g_sdf, None, None, None, None, None, None, None
+        return g_depth, g_rgb, g_sdf, None, None, None, None, None, None, None, None

@@ -58,7 +58,12 @@ class FlatGrads:
 
 
 class ShardedMapper:
-    """Drives one ray-sharded mapping iteration on this rank's shard (a harness.Workload holding this rank's rays)."""
+    """Drives one ray-sharded mapping iteration on this rank's shard (a harness.Workload holding this rank's rays).
+
+    step() = phase_a (sample, render forward, eslam_loss_reduce) -> all-reduce of the 16 loss accumulators ->
+    phase_b (loss value, eslam_loss_grad, render backward into the flat gradient buffer) -> all-reduce of that buffer.
+    The two phases contain no collective, so each can be captured into a hipGraph of its own (capture()); the two
+    all-reduces are issued eagerly between the replays - RCCL never has to run inside a captured graph."""
 
     def __init__(self, workload, group=None):
         from . import losses
@@ -71,17 +76,60 @@ class ShardedMapper:
         if self.has_beta:
             self.params = self.params + [beta]
         self.grads = FlatGrads(self.params)
+        self.acc = torch.zeros(16, device=workload.device)
+        self._out = None
+        self._graphs = None
+        self.loss = None
 
-    def step(self):
+    def phase_a(self):
         wl = self.wl
         for p in self.params:
             p.grad = None
+        self._out = wl.renderer.render_batch_ray(wl.planes, wl.decoders, wl.rays_d, wl.rays_o, wl.device, wl.truncation,
+                                                 gt_depth=wl.gt_depth)
+        depth, color, sdf, z = self._out
+        ops.loss_reduce(depth, color, sdf, z, wl.gt_depth, wl.gt_color, wl.truncation, None, self.acc)
+
+    def phase_b(self):
+        wl = self.wl
+        depth, color, sdf, z = self._out
         with ops.grad_sink(self.grads):
-            depth, color, sdf, z = wl.renderer.render_batch_ray(wl.planes, wl.decoders, wl.rays_d, wl.rays_o, wl.device,
-                                                                wl.truncation, gt_depth=wl.gt_depth)
-            loss = ops.MappingLossFn.apply(depth, color, sdf, z, wl.gt_depth, wl.gt_color, wl.truncation, self.weights,
-                                           None, True if self.group is None else self.group)
-            loss.backward()
+            self.loss = ops.MappingLossFn.apply(depth, color, sdf, z, wl.gt_depth, wl.gt_color, wl.truncation,
+                                                self.weights, None, None, self.acc)
+            self.loss.backward()
+
+    def _eager(self):
+        self.phase_a()
+        dist.all_reduce(self.acc, op=dist.ReduceOp.SUM, group=self.group)
+        self.phase_b()
         self.grads.all_reduce(self.group)
         self.grads.assign()
-        return loss
+        return self.loss
+
+    def capture(self, warmup=3):
+        """Capture phase_a and phase_b into two hipGraphs sharing one memory pool; step() then replays them."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+            self.phase_a()
+        with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
+            self.phase_b()
+        torch.cuda.synchronize()
+        self._graphs = (ga, gb)
+
+    def step(self):
+        if self._graphs is None:
+            return self._eager()
+        ga, gb = self._graphs
+        ga.replay()
+        dist.all_reduce(self.acc, op=dist.ReduceOp.SUM, group=self.group)
+        gb.replay()
+        self.grads.all_reduce(self.group)
+        self.grads.assign()
+        return self.loss

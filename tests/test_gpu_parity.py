@@ -310,6 +310,14 @@ def test_sharded_mapper_one_rank_rccl():
         for a, b in zip(g_dp, g_ref):
             assert a.stride() == b.stride()
             assert hp.rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 2e-5
+        # the same step as two captured hipGraphs with the all-reduces between the replays
+        mapper.capture()
+        for _ in range(2):
+            loss_g = mapper.step()
+        torch.cuda.synchronize()
+        assert abs(float(loss_g) - float(loss)) <= 1e-6 * abs(float(loss))
+        for p, b in zip(mapper.params, g_ref):
+            assert hp.rel_err(p.grad.cpu().numpy(), b.cpu().numpy()) <= 2e-5
     finally:
         dist.destroy_process_group()
 
