@@ -300,8 +300,11 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const eslam_decoders_t dec
     }
 
     if (!WGRAD) return;
-    // per-wave slab: [wave_global][decoder] -> SLAB floats
-    float* sl = slabs + (((int64_t)blockIdx.x * 4 + wave) * 2 + d) * SLAB;
+    // the four waves' partial parameter gradients are summed in LDS; one slab row per workgroup: [wg][decoder][SLAB]
+    __shared__ __attribute__((aligned(16))) float comb[4][SLAB];
+    float* sl = comb[wave];
+    for (int i = lane; i < SLAB; i += WAVE) sl[i] = 0.0f;       // unwritten padding columns must not hold NaN bit patterns
+    WAVE_SYNC();
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int j = 4 * q + reg;
@@ -331,6 +334,10 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const eslam_decoders_t dec
         const float t = wave_sum(gb3[o]);
         if (lane == 0 && o < nout) sl[SL_B3 + o] = t;
     }
+    __syncthreads();
+    float* row = slabs + ((int64_t)blockIdx.x * 2 + d) * SLAB;
+    for (int col = threadIdx.x; col < SLAB; col += 256)     // columns no wave writes (padding) are never read back
+        row[col] = (comb[0][col] + comb[1][col]) + (comb[2][col] + comb[3][col]);
 }
 
 __global__ __launch_bounds__(1024) void beta_sum_kernel(const float* __restrict__ parts, int n, float* __restrict__ out) {
@@ -614,7 +621,7 @@ static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, 
         rs = aux->stream;
     }
     eslam_prof_begin(PROF_DEC_REDUCE, rs);
-    hipLaunchKernelGGL(dec_grad_reduce_kernel, dim3((SLAB + 63) / 64, 2), dim3(1024), 0, rs, slabs, nwg * 4, g_dec,
+    hipLaunchKernelGGL(dec_grad_reduce_kernel, dim3((SLAB + 63) / 64, 2), dim3(1024), 0, rs, slabs, nwg, g_dec,
                        beta_parts, n_beta_parts, g_beta);
     eslam_prof_end(PROF_DEC_REDUCE, rs);
     if (int rc = eslam_check_launch("dec_grad_reduce_kernel")) return rc;
