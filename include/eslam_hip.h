@@ -114,6 +114,14 @@ int eslam_render_fwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, c
                      float* rgb, float* sdf, float* raw_rgb, float* feat, const int32_t* ray_order,
                      eslam_stream_t stream);
 
+/* Mixed-precision forward for inference (BASELINE.json configs[4], a tolerance study): planes_f16[i].data points to
+ * IEEE-half data of a channels-last [1,32,h,w] plane (strides in half elements: stride_c = 1, stride_x = 32), the decoder
+ * weights are rounded to bf16 inside the kernel and run on bf16 MFMA with float32 accumulation; everything after the MLPs
+ * (activations, alpha, transmittance, composite) is float32.  Same outputs as eslam_render_fwd; no backward.        */
+int eslam_render_fwd_lowp(const eslam_plane_t* planes_f16, const eslam_decoders_t* dec, const float* bound6_host,
+                          const float* rays_o, const float* rays_d, const float* z_vals, int R, int S, float* depth,
+                          float* rgb, float* sdf, eslam_stream_t stream);
+
 /* Ray order for eslam_render_fwd / eslam_render_bwd: perm [R] <- ray ids sorted by a 15-bit Morton key of the point one
  * metre along each ray (single-pass counting sort, chunks of 8192 rays).  Depends only on the rays, so a caller can
  * run it on a side stream next to the samplers.                                                              */

@@ -46,6 +46,7 @@ SIGNATURES = {
     "eslam_sample_z": (_i, [_vp, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp]),
     "eslam_importance_z": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "eslam_render_fwd": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "eslam_render_fwd_lowp": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "eslam_ray_order": (_i, [_vp, _vp, _i, _vp, _vp]),
     "eslam_bwd_workspace_bytes": (_i64, [_i64]),
     "eslam_render_bwd": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -113,7 +114,7 @@ def require_gpu_f32(name, t):
         raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
 
 
-def make_planes(all_planes, grads=None):
+def make_planes(all_planes, grads=None, dtype=torch.float32):
     """all_planes: the reference's 6-tuple of [coarse, fine] lists -> (PlaneArray, keepalive list)."""
     arr = PlaneArray()
     flat = []
@@ -124,7 +125,10 @@ def make_planes(all_planes, grads=None):
             raise RuntimeError(f"plane group {g}: expected [coarse, fine], got {len(grp)} levels")
         for lvl in range(2):
             p = grp[lvl]
-            require_gpu_f32(f"plane[{g}][{lvl}]", p)
+            if dtype == torch.float32:
+                require_gpu_f32(f"plane[{g}][{lvl}]", p)
+            elif not p.is_cuda or p.dtype != dtype:
+                raise RuntimeError(f"plane[{g}][{lvl}]: expected a {dtype} tensor on the GPU, got {p.dtype} on {p.device}")
             if p.dim() != 4 or p.shape[0] != 1 or p.shape[1] != 32:
                 raise RuntimeError(f"plane[{g}][{lvl}]: expected shape [1,32,h,w], got {tuple(p.shape)}")
             d = arr[k]

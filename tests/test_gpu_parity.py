@@ -425,3 +425,29 @@ def test_edge_shapes_against_oracle(R, ns, ni, zero_frac):
     for k, t in wl.decoders.named_parameters():
         ref = cbeta.grad if k == "beta" else cparams[k].grad
         assert hp.rel_err(t.grad.cpu().numpy(), ref.numpy()) <= RTOL, k
+
+
+def test_mixed_precision_tolerance_study():
+    """BASELINE.json configs[4]: freiburg1_desk, 5000 rays x 56 samples, fp16 planes + bf16 MFMA decoders vs the float32
+    path on the same rays and z_vals.  This is a tolerance STUDY: the bounds below are what the formats allow (half has 11
+    significant bits, bf16 8), recorded in DESIGN.md - not the 1e-4 parity bar, which only the float32 path is held to."""
+    from myslam_amd import lowp
+    fx = hp.load("freiburg1_desk_5000x56_zero10")
+    dev = _dev()
+    sc, planes, dec, renderer = build(fx, planes_grad=False, dec_grad=False)
+    t_rand, t_uni, u = hp.rand_inputs(fx)
+    rand = tuple(None if t is None else t.to(dev) for t in (t_rand, t_uni, u))
+    ro = torch.from_numpy(fx["rays_o"]).to(dev)
+    rd = torch.from_numpy(fx["rays_d"]).to(dev)
+    gd = torch.from_numpy(fx["gt_depth"]).to(dev)
+    tr = float(fx["truncation"])
+    with torch.no_grad():
+        d32, c32, s32, z32 = renderer.render_batch_ray(planes, dec, rd, ro, dev, tr, gt_depth=gd, _rand=rand)
+    ph = lowp.half_planes(planes)
+    d16, c16, s16, z16 = lowp.render_batch_ray_lowp(renderer, planes, ph, dec, rd, ro, tr, gd, _rand=rand)
+    assert torch.equal(z16, z32)
+    e_sdf = float((s16 - s32).abs().max())
+    e_rgb = float((c16 - c32).abs().max())
+    e_dep = float(((d16 - d32).abs() / d32.abs().clamp(min=1e-3)).max())
+    print(f"mixed precision vs float32: max|sdf| {e_sdf:.2e}  max|rgb| {e_rgb:.2e}  max rel depth {e_dep:.2e}")
+    assert e_sdf < 5e-3 and e_rgb < 5e-3 and e_dep < 2e-2

@@ -42,3 +42,22 @@ pts = (torch.rand(500000, 3, device=dev) * (wl.scene.bound[:, 1] - wl.scene.boun
 with torch.no_grad():
     t = timed(lambda: wl.decoders(pts, all_planes=wl.planes), n=10, warm=3)
 print(f"Decoders.forward 500k points: {t:.3f} ms  ({500000/t*1e3:.3e} points/s)")
+
+# mixed precision forward (configs[4]) vs float32 forward, inference, 4096 x 64 and a whole image in one chunk
+from myslam_amd import lowp
+wl2 = harness.make_workload('room0', 4096, 56, 8, device=dev)
+ph = lowp.half_planes(wl2.planes)
+rand = wl2._rand
+def f32():
+    with torch.no_grad():
+        wl2.renderer.render_batch_ray(wl2.planes, wl2.decoders, wl2.rays_d, wl2.rays_o, dev, wl2.truncation, gt_depth=wl2.gt_depth, _rand=rand)
+def f16():
+    lowp.render_batch_ray_lowp(wl2.renderer, wl2.planes, ph, wl2.decoders, wl2.rays_d, wl2.rays_o, wl2.truncation, wl2.gt_depth, _rand=rand)
+buf = (ctypes.c_float * 10)()
+for name, fn in (('float32', f32), ('fp16 planes + bf16 MFMA', f16)):
+    for _ in range(5): fn()
+    ts = []
+    for _ in range(20):
+        lib.eslam_profile_enable(1); fn(); torch.cuda.synchronize(); lib.eslam_profile_read(buf); ts.append(buf[0])
+    lib.eslam_profile_enable(0)
+    print(f"forward kernel 4096x64 inference, {name}: {sorted(ts)[10]*1e3:.1f} us")
