@@ -106,6 +106,22 @@ def stream_handle(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL = _NullCtx()
+
+
+def on_device(device):
+    """Context that makes `device` current for a launch; free when it already is (torch.cuda.device costs ~15 us)."""
+    return _NULL if torch.cuda.current_device() == device.index else torch.cuda.device(device)
+
+
 def require_gpu_f32(name, t):
     if not t.is_cuda:
         raise RuntimeError(f"{name}: expected a tensor on the GPU (got device {t.device}); the HIP render path has "
@@ -114,17 +130,24 @@ def require_gpu_f32(name, t):
         raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
 
 
+_plane_cache = {}
+
+
 def make_planes(all_planes, grads=None, dtype=torch.float32):
-    """all_planes: the reference's 6-tuple of [coarse, fine] lists -> (PlaneArray, keepalive list)."""
-    arr = PlaneArray()
-    flat = []
-    k = 0
-    for g in range(6):
-        grp = all_planes[g]
-        if len(grp) != 2:
-            raise RuntimeError(f"plane group {g}: expected [coarse, fine], got {len(grp)} levels")
-        for lvl in range(2):
-            p = grp[lvl]
+    """all_planes: the reference's 6-tuple of [coarse, fine] lists -> (PlaneArray, keepalive list).
+
+    Descriptors are cached per (data pointers, shapes, row strides): the mapper keeps the same 12 storages for a whole
+    run (it re-wraps them as new nn.Parameters every frame, src/Mapper.py:254-266, without moving them), and building
+    12 ctypes structs from tensor attributes costs ~25 us of host time per call otherwise."""
+    flat = [p for grp in all_planes for p in grp]
+    if len(flat) != N_PLANES or any(len(grp) != 2 for grp in all_planes):
+        raise RuntimeError("all_planes must be 6 groups of [coarse, fine] planes")
+    key = (dtype,) + tuple((p.data_ptr(), p.shape[2], p.shape[3], p.stride(2)) for p in flat)
+    hit = _plane_cache.get(key)
+    if hit is None:
+        arr = PlaneArray()
+        for k, p in enumerate(flat):
+            g, lvl = divmod(k, 2)
             if dtype == torch.float32:
                 require_gpu_f32(f"plane[{g}][{lvl}]", p)
             elif not p.is_cuda or p.dtype != dtype:
@@ -135,15 +158,16 @@ def make_planes(all_planes, grads=None, dtype=torch.float32):
             d.data = p.data_ptr()
             d.h, d.w = int(p.shape[2]), int(p.shape[3])
             d.stride_c, d.stride_y, d.stride_x = (int(v) for v in p.stride()[1:])
-            if grads is not None:
-                gr = grads[k]
-                if gr.stride() != p.stride() or gr.shape != p.shape:
-                    raise RuntimeError("plane gradient buffer must have the plane's shape and strides")
-                d.grad = gr.data_ptr()
-            else:
-                d.grad = None
-            flat.append(p)
-            k += 1
+            d.grad = None
+        if len(_plane_cache) > 64:
+            _plane_cache.clear()
+        hit = _plane_cache[key] = (bytes(arr), [tuple(p.shape) for p in flat], [p.stride() for p in flat])
+    arr = PlaneArray.from_buffer_copy(hit[0])
+    if grads is not None:
+        for k, gr in enumerate(grads):
+            if gr.shape != hit[1][k] or gr.stride() != hit[2][k]:
+                raise RuntimeError("plane gradient buffer must have the plane's shape and strides")
+            arr[k].grad = gr.data_ptr()
     return arr, flat
 
 
@@ -155,22 +179,28 @@ DEC_FIELDS = (("w1", "linears.0.weight", (16, 64)), ("b1", "linears.0.bias", (16
               ("cw3", "c_output_linear.weight", (3, 16)), ("cb3", "c_output_linear.bias", (3,)))
 
 
+_dec_cache = {}
+
+
 def make_decoders(params, beta):
-    """params: 12 tensors in DEC_FIELDS order; beta: device tensor [1]."""
-    d = DecodersDesc()
-    keep = []
-    for (field, name, shape), t in zip(DEC_FIELDS, params):
-        require_gpu_f32(name, t)
-        if tuple(t.shape) != shape:
-            raise RuntimeError(f"{name}: expected shape {shape}, got {tuple(t.shape)} (c_dim=32, hidden=16, 2 blocks)")
-        if not t.is_contiguous():
-            t = t.contiguous()
-        keep.append(t)
-        setattr(d, field, t.data_ptr())
-    require_gpu_f32("beta", beta)
-    d.beta = beta.data_ptr()
-    keep.append(beta)
-    return d, keep
+    """params: 12 tensors in DEC_FIELDS order; beta: device tensor [1].  Cached per set of data pointers."""
+    key = tuple(t.data_ptr() for t in params) + (beta.data_ptr(),)
+    d = _dec_cache.get(key)
+    if d is None:
+        d = DecodersDesc()
+        for (field, name, shape), t in zip(DEC_FIELDS, params):
+            require_gpu_f32(name, t)
+            if tuple(t.shape) != shape:
+                raise RuntimeError(f"{name}: expected shape {shape}, got {tuple(t.shape)} (c_dim=32, hidden=16, 2 blocks)")
+            if not t.is_contiguous():
+                raise RuntimeError(f"{name}: decoder parameters must be contiguous")
+            setattr(d, field, t.data_ptr())
+        require_gpu_f32("beta", beta)
+        d.beta = beta.data_ptr()
+        if len(_dec_cache) > 64:
+            _dec_cache.clear()
+        _dec_cache[key] = d
+    return d, (params, beta)
 
 
 def make_bound(bound_host):

@@ -33,7 +33,7 @@ def render_batch_ray_lowp(renderer, all_planes, planes_f16, decoders, rays_d, ra
         rgb = torch.empty(R, 3, device=dev)
         sdf = torch.empty(R, S, device=dev)
         ro, rd = rays_o.detach().contiguous(), rays_d.detach().contiguous()
-        with torch.cuda.device(dev):
+        with _hip.on_device(dev):
             _hip.check(_hip.lib().eslam_render_fwd_lowp(arr, ctypes.byref(dec), _hip.make_bound(ops.bound_to_host(decoders.bound)),
                                                         _hip.ptr(ro), _hip.ptr(rd), _hip.ptr(z_vals), R, S, _hip.ptr(depth),
                                                         _hip.ptr(rgb), _hip.ptr(sdf), _hip.stream_handle(dev)),

@@ -77,30 +77,36 @@ class grad_sink:
         _grad_sink = self._prev
 
 
+_grad_layout_cache = {}
+
+
 def _alloc_plane_grads(planes):
     """One flat zero buffer, 12 views with the planes' own strides (so autograd can adopt them without a copy
     and a multi-GPU caller can all-reduce the flat buffer)."""
-    sizes = [p.numel() for p in planes]
-    flat = torch.zeros(sum(sizes), device=planes[0].device, dtype=torch.float32)
-    views, off = [], 0
-    for p, n in zip(planes, sizes):
-        dense = p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last)
-        if not dense:
-            raise RuntimeError("planes must be dense (contiguous or channels_last)")
-        views.append(flat[off:off + n].as_strided(p.shape, p.stride()))
-        off += n
-    return flat, views
+    key = tuple((tuple(p.shape), p.stride()) for p in planes)
+    layout = _grad_layout_cache.get(key)
+    if layout is None:
+        off, layout = 0, []
+        for p in planes:
+            if not (p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last)):
+                raise RuntimeError("planes must be dense (contiguous or channels_last)")
+            layout.append((tuple(p.shape), p.stride(), off))
+            off += p.numel()
+        layout = _grad_layout_cache[key] = (layout, off)
+    entries, total = layout
+    flat = torch.zeros(total, device=planes[0].device, dtype=torch.float32)
+    return flat, [torch.as_strided(flat, shp, st, off) for shp, st, off in entries]
+
+
+_DEC_SIZES = [16 * 64, 16, 16 * 16, 16, 16, 1, 16 * 64, 16, 16 * 16, 16, 48, 3]
 
 
 def _split_dec_grads(g_dec):
-    out, off = [], 0
-    for _, _, shape in _hip.DEC_FIELDS:
-        n = 1
-        for s in shape:
-            n *= s
-        out.append(g_dec[off:off + n].view(shape))
-        off += n
-    return out
+    parts = g_dec.split(_DEC_SIZES)
+    return [t.view(shape) if len(shape) > 1 else t for t, (_, _, shape) in zip(parts, _hip.DEC_FIELDS)]
+
+
+_dec_param_cache = {}
 
 
 _side_streams = {}
@@ -120,7 +126,7 @@ def ray_order_async(rays_o, rays_d):
     perm = torch.empty(R, dtype=torch.int32, device=dev)
     cur = torch.cuda.current_stream(dev)
     side.wait_stream(cur)
-    with torch.cuda.device(dev), torch.cuda.stream(side):
+    with _hip.on_device(dev), torch.cuda.stream(side):
         _hip.check(_hip.lib().eslam_ray_order(_hip.ptr(ro), _hip.ptr(rd), R, _hip.ptr(perm),
                                               ctypes.c_void_p(side.cuda_stream)), "eslam_ray_order")
     perm.record_stream(side)
@@ -154,7 +160,7 @@ class RenderFn(torch.autograd.Function):
         if order_in is not None:
             order, side = order_in
             torch.cuda.current_stream(dev).wait_stream(side)
-        with torch.cuda.device(dev):
+        with _hip.on_device(dev):
             _hip.check(lib.eslam_render_fwd(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(rays_o),
                                             _hip.ptr(rays_d), _hip.ptr(z_vals), R, S, _hip.ptr(depth), _hip.ptr(rgb),
                                             _hip.ptr(sdf), _hip.ptr(raw_rgb), _hip.ptr(feat), _hip.ptr(order),
@@ -198,7 +204,7 @@ class RenderFn(torch.autograd.Function):
         g_rd = torch.empty(R, 3, device=dev) if need_rays else None
         ws = torch.empty(lib.eslam_bwd_workspace_bytes(R * S), dtype=torch.uint8, device=dev)
         g_depth, g_rgb, g_sdf = _c(g_depth), _c(g_rgb), _c(g_sdf)
-        with torch.cuda.device(dev):
+        with _hip.on_device(dev):
             _hip.check(lib.eslam_render_bwd(arr, ctypes.byref(dec), _hip.make_bound(ctx.bound6), _hip.ptr(rays_o),
                                             _hip.ptr(rays_d), _hip.ptr(z_vals), R, S, _hip.ptr(sdf), _hip.ptr(raw_rgb),
                                             _hip.ptr(feat), _hip.ptr(g_depth), _hip.ptr(g_rgb), _hip.ptr(g_sdf),
@@ -231,7 +237,7 @@ class DecodeFn(torch.autograd.Function):
         needs = any(ctx.needs_input_grad)
         raw = torch.empty(N, 4, device=dev)
         feat = torch.empty(N, 128, device=dev) if needs else None
-        with torch.cuda.device(dev):
+        with _hip.on_device(dev):
             _hip.check(lib.eslam_decode_fwd(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(pts), N, 0,
                                             _hip.ptr(raw), _hip.ptr(feat), _hip.stream_handle(dev)), "eslam_decode_fwd")
         if needs:
@@ -258,7 +264,7 @@ class DecodeFn(torch.autograd.Function):
         g_pts = torch.empty(N, 3, device=dev) if need[0] else None
         ws = torch.empty(lib.eslam_bwd_workspace_bytes(N), dtype=torch.uint8, device=dev)
         g_raw = _c(g_raw)
-        with torch.cuda.device(dev):
+        with _hip.on_device(dev):
             _hip.check(lib.eslam_decode_bwd(arr, ctypes.byref(dec), _hip.make_bound(ctx.bound6), _hip.ptr(pts), N,
                                             _hip.ptr(raw), _hip.ptr(feat), _hip.ptr(g_raw), _hip.ptr(g_dec),
                                             _hip.ptr(g_pts), _hip.ptr(ws), _hip.stream_handle(dev)), "eslam_decode_bwd")
@@ -280,7 +286,7 @@ def decode_sdf_only(pts, bound6, all_planes, decoders):
     arr, _ = _hip.make_planes(tuple([p.detach() for p in grp] for grp in geo))
     dec, keep = _hip.make_decoders([p.detach() for p in decoder_params(decoders)], beta_tensor(10, dev))
     out = torch.empty(N, device=dev)
-    with torch.cuda.device(dev):
+    with _hip.on_device(dev):
         _hip.check(lib.eslam_decode_fwd(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(pts), N, 1,
                                         _hip.ptr(out), None, _hip.stream_handle(dev)), "eslam_decode_fwd(sdf)")
     return out
@@ -308,7 +314,7 @@ class SampleRaysFn(torch.autograd.Function):
         rd = torch.empty(b * n, 3, device=dev)
         d = torch.empty(b * n, device=dev)
         c = torch.empty(b * n, 3, device=dev)
-        with torch.cuda.device(dev):
+        with _hip.on_device(dev):
             _hip.check(_hip.lib().eslam_sample_rays(_hip.ptr(indices), b, n, H0, H1, W0, W1, H, W, fx, fy, cx, cy,
                                                     _hip.ptr(c2), _hip.ptr(depths), _hip.ptr(colors), _hip.ptr(ro),
                                                     _hip.ptr(rd), _hip.ptr(d), _hip.ptr(c), _hip.stream_handle(dev)),
@@ -326,7 +332,7 @@ class SampleRaysFn(torch.autograd.Function):
         dev = indices.device
         g = torch.empty(ctx.b, 4, 4, device=dev)
         g_ro, g_rd = _c(g_ro), _c(g_rd)
-        with torch.cuda.device(dev):
+        with _hip.on_device(dev):
             _hip.check(_hip.lib().eslam_sample_rays_bwd(_hip.ptr(indices), ctx.b, n, H0, W0, W1, fx, fy, cx, cy,
                                                         _hip.ptr(g_ro), _hip.ptr(g_rd), _hip.ptr(g),
                                                         _hip.stream_handle(dev)), "eslam_sample_rays_bwd")
@@ -339,7 +345,7 @@ def image_rays(H, W, fx, fy, cx, cy, c2w):
     dev = c2.device
     ro = torch.empty(H * W, 3, device=dev)
     rd = torch.empty(H * W, 3, device=dev)
-    with torch.cuda.device(dev):
+    with _hip.on_device(dev):
         _hip.check(_hip.lib().eslam_image_rays(H, W, fx, fy, cx, cy, _hip.ptr(c2), _hip.ptr(ro), _hip.ptr(rd),
                                                _hip.stream_handle(dev)), "eslam_image_rays")
     return ro, rd
@@ -350,7 +356,7 @@ def aabb_exit(rays_o, rays_d, bound6):
     ro, rd = _c(rays_o.detach()), _c(rays_d.detach())
     R = ro.shape[0]
     t = torch.empty(R, device=ro.device)
-    with torch.cuda.device(ro.device):
+    with _hip.on_device(ro.device):
         _hip.check(_hip.lib().eslam_aabb_exit(_hip.ptr(ro), _hip.ptr(rd), R, _hip.make_bound(bound6), _hip.ptr(t),
                                               _hip.stream_handle(ro.device)), "eslam_aabb_exit")
     return t
@@ -378,7 +384,7 @@ def sample_z(rays_o, rays_d, gt_depth, all_planes, decoders, bound6, truncation,
         t_rand, t_uni, u = (None if t is None else _c(t) for t in rand)
     z = torch.empty(R, S, device=dev)
     t_free, t_surf = linspace01(n_strat, dev), linspace01(n_imp, dev)
-    with torch.cuda.device(dev):
+    with _hip.on_device(dev):
         st = _hip.stream_handle(dev)
         _hip.check(lib.eslam_sample_z(_hip.ptr(gd), R, n_strat, n_imp, float(truncation), _hip.ptr(t_free),
                                       _hip.ptr(t_surf), _hip.ptr(t_rand), _hip.ptr(z), st), "eslam_sample_z")
@@ -406,7 +412,7 @@ def loss_reduce(depth, rgb, sdf, z_vals, gt_depth, gt_color, truncation, ray_mas
         acc = torch.zeros(16, device=dev)
     else:
         acc.zero_()
-    with torch.cuda.device(dev):
+    with _hip.on_device(dev):
         _hip.check(_hip.lib().eslam_loss_reduce(*[_hip.ptr(t) for t in args], R, S, float(truncation), _hip.ptr(ray_mask),
                                                 _hip.ptr(acc), _hip.stream_handle(dev)), "eslam_loss_reduce")
     return acc
@@ -435,7 +441,7 @@ class MappingLossFn(torch.autograd.Function):
         args = [_c(t.detach()) for t in (depth, rgb, sdf, z_vals, gt_depth, gt_color)]
         loss = torch.empty(1, device=dev)
         w = (ctypes.c_float * 5)(*[float(v) for v in weights5])
-        with torch.cuda.device(dev):
+        with _hip.on_device(dev):
             _hip.check(_hip.lib().eslam_loss_grad(*[_hip.ptr(t) for t in args], R, S, float(truncation), w,
                                                   _hip.ptr(ray_mask), _hip.ptr(acc), _hip.ptr(loss), None, None, None,
                                                   None, _hip.stream_handle(dev)), "eslam_loss_grad(value)")
@@ -455,7 +461,7 @@ class MappingLossFn(torch.autograd.Function):
         g_sdf = torch.empty(R, S, device=dev)
         w = (ctypes.c_float * 5)(*weights5)
         g = _c(g.detach().reshape(1).to(torch.float32))
-        with torch.cuda.device(dev):
+        with _hip.on_device(dev):
             _hip.check(_hip.lib().eslam_loss_grad(*[_hip.ptr(t) for t in args], R, S, truncation, w,
                                                   _hip.ptr(ctx.ray_mask), _hip.ptr(acc), None, _hip.ptr(g_depth),
                                                   _hip.ptr(g_rgb), _hip.ptr(g_sdf), _hip.ptr(g),
