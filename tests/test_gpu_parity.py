@@ -451,3 +451,63 @@ def test_mixed_precision_tolerance_study():
     e_dep = float(((d16 - d32).abs() / d32.abs().clamp(min=1e-3)).max())
     print(f"mixed precision vs float32: max|sdf| {e_sdf:.2e}  max|rgb| {e_rgb:.2e}  max rel depth {e_dep:.2e}")
     assert e_sdf < 5e-3 and e_rgb < 5e-3 and e_dep < 2e-2
+
+
+def test_multi_camera_batch_against_oracle():
+    """A mapping batch as the reference forms it (src/Mapper.py:318-319): rays of several keyframes with different poses
+    in one call.  Exercises the ray ordering / bundling with several origins and directions; compared in full with
+    autograd over the float64 oracle."""
+    from oracle import eslam_oracle as orc
+    from myslam_amd import harness, scene as scn, synth, losses
+    from myslam_amd.src.common import get_samples_at
+    dev = _dev()
+    wl = harness.make_workload("room0", 64, 32, 8, device=dev, planes="synth")
+    sc = wl.scene
+    b, n = 6, 150
+    c2ws = torch.eye(4).repeat(b, 1, 1)
+    for i in range(b):
+        m = synth.hash_uniform((3, 3), 300 + i).astype(np.float64) - 0.5
+        qm, rm = np.linalg.qr(m)
+        qm = qm * np.sign(np.diag(rm))
+        if np.linalg.det(qm) < 0:
+            qm[:, 0] = -qm[:, 0]
+        c2ws[i, :3, :3] = torch.from_numpy(qm).float()
+        c2ws[i, :3, 3] = sc.bound.mean(1) + (torch.from_numpy(synth.hash_uniform((3,), 320 + i)) - 0.5) * 2.0
+    c2ws = c2ws.to(dev)
+    depth_img = torch.from_numpy(np.stack([synth.depth_image(sc.H, sc.W, 330 + i, 0.1) for i in range(b)])).to(dev)
+    color_img = torch.from_numpy(np.stack([synth.color_image(sc.H, sc.W, 340 + i) for i in range(b)])).to(dev)
+    idx = torch.from_numpy(synth.hash_randint(sc.H * sc.W, (b * n,), 350)).to(dev)
+    with torch.no_grad():
+        ro, rd, gd, gc = get_samples_at(idx, 0, sc.H, 0, sc.W, n, sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, c2ws,
+                                        depth_img, color_img)
+    R, S = ro.shape[0], wl.S
+    rand = (torch.from_numpy(synth.hash_uniform((R, S), 360)).to(dev), torch.from_numpy(synth.hash_uniform((R, 32), 361)).to(dev),
+            torch.from_numpy(synth.hash_uniform((R, 8), 362)).to(dev))
+    depth, color, sdf, z = wl.renderer.render_batch_ray(wl.planes, wl.decoders, rd, ro, dev, wl.truncation, gt_depth=gd,
+                                                        _rand=rand)
+    losses.mapping_loss(depth, color, sdf, z, gd, gc, wl.truncation).backward()
+    def oracle_run(dtype):
+        cv = lambda t: t.detach().cpu().to(dtype)
+        planes = tuple([cv(p).contiguous().requires_grad_(True) for p in grp] for grp in wl.planes)
+        params = {k: cv(v).requires_grad_(True) for k, v in wl.decoders.state_dict().items() if k != "beta"}
+        beta = cv(wl.decoders.beta).requires_grad_(True)
+        od, oc, os_, _ = orc.render_batch_ray(planes, params, beta, sc.bound, cv(rd), cv(ro), wl.truncation, cv(gd), 32, 8,
+                                              z_vals=cv(z))
+        orc.mapping_loss(od, oc, os_, cv(z), cv(gd), cv(gc), wl.truncation).backward()
+        grads = [p.grad.double().numpy() for p in hp.flat_planes(planes)]
+        grads += [(beta.grad if k == "beta" else params[k].grad).double().numpy() for k, _ in wl.decoders.named_parameters()]
+        return od.detach().double().numpy(), oc.detach().double().numpy(), grads
+
+    od, oc, g64 = oracle_run(torch.float64)
+    _, _, g32 = oracle_run(torch.float32)
+    assert hp.rel_err(depth.detach().cpu().numpy(), od) <= RTOL
+    assert hp.rel_err(color.detach().cpu().numpy(), oc) <= RTOL
+    mine = [p.grad.cpu().double().numpy() for p in wl.plane_list] + [t.grad.cpu().double().numpy() for _, t in wl.decoders.named_parameters()]
+    # With 200x-weighted sdf terms on a handful of samples, one hidden unit whose pre-activation sits within float32
+    # rounding of zero moves the first-layer / sdf-plane gradients by ~1e-3 of their maximum between float32 and
+    # float64 arithmetic (measured: the float32 oracle is 7e-4..1.8e-3 away from the float64 one on exactly those
+    # tensors, and the kernels are 6e-7 away from the float32 oracle).  The reference computes in float32, so the
+    # float32 oracle is the comparator; the float64 one bounds how far both may be from exact.
+    for k, (a, r32, r64) in enumerate(zip(mine, g32, g64)):
+        assert hp.rel_err(a, r32) <= RTOL, k
+        assert hp.rel_err(a, r64) <= max(RTOL, 1.5 * hp.rel_err(r32, r64)), k
