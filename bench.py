@@ -50,13 +50,13 @@ def kernel_profile(step_fn, iters):
     from myslam_amd import _hip
     lib = _hip.lib()
     sums, cnt = {}, {}
-    buf = (ctypes.c_float * 10)()
+    buf = (ctypes.c_float * 12)()
     for _ in range(iters):
         _hip.check(lib.eslam_profile_enable(1), "profile_enable")
         step_fn()
         torch.cuda.synchronize()
         _hip.check(lib.eslam_profile_read(buf), "profile_read")
-        for i in range(10):
+        for i in range(12):
             if buf[i] >= 0:
                 n = lib.eslam_profile_name(i).decode()
                 sums[n] = sums.get(n, 0.0) + buf[i]

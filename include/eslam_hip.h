@@ -186,10 +186,36 @@ int eslam_loss_grad(const float* depth, const float* rgb, const float* sdf, cons
                     const float* weights5_host, const uint8_t* ray_mask, const float* acc, float* loss,
                     float* g_depth, float* g_rgb, float* g_sdf, const float* upstream, eslam_stream_t stream);
 
+/* Optimiser step of the callers' loops: torch.optim.Adam exactly as the reference
+ * builds it - default betas (0.9, 0.999) and eps 1e-8 unless given, no weight decay, no amsgrad - over all
+ * parameter tensors of one step in ONE launch.  Replaces `optimizer.step()` (+ optionally `optimizer.zero_grad()`)
+ * of src/Mapper.py:291-303,348-350 (decoders / planes / c_planes / camera-pose groups, one lr each) and of
+ * src/Tracker.py:262-266,206-208 (cam_pose translation / rotation groups).
+ *   tensors_host: HOST array of n_tensors descriptors; each names four dense device arrays of n float32 in the
+ *                 same element order (param, grad, exp_avg, exp_avg_sq) and the lr of the tensor's param group;
+ *   step:         1-based step count t of the bias corrections (state['step'] after the increment), used when
+ *                 step_dev is NULL;
+ *   step_dev:     optional device int32 counter: incremented by one on the stream and then used as t, so that a
+ *                 captured hipGraph can be replayed without re-recording (t never appears in the kernel arguments);
+ *   zero_grad:    non-zero = clear every consumed gradient in the same pass.
+ * Elements whose grad, exp_avg and exp_avg_sq are all zero are skipped - the dense update leaves them unchanged
+ * bit for bit.  Tensors whose four pointers are 16-byte aligned take the float4 path.                          */
+#define ESLAM_ADAM_MAX_TENSORS 32   /* descriptors per launch; longer tables are split into several launches */
+typedef struct {
+    float* param;
+    float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t n;
+    double lr;
+} eslam_adam_tensor_t;
+int eslam_adam_step(const eslam_adam_tensor_t* tensors_host, int n_tensors, int step, int32_t* step_dev,
+                    double beta1, double beta2, double eps, int zero_grad, eslam_stream_t stream);
+
 /* Per-kernel device timing for bench.py's roofline line (HIP events recorded on the launch stream around each
  * kernel while enabled; adds nothing to the launch path when disabled).  Usage: enable(1); run one iteration;
  * synchronise the stream; read(ms) -> elapsed milliseconds of the LAST launch of each kernel, -1 if it did not run. */
-#define ESLAM_PROF_KERNELS 10
+#define ESLAM_PROF_KERNELS 12
 int eslam_profile_enable(int on);
 int eslam_profile_read(float* ms_out);
 const char* eslam_profile_name(int kernel_id);

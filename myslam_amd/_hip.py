@@ -59,7 +59,16 @@ SIGNATURES = {
     "eslam_profile_read": (_i, [_BP]),
     "eslam_profile_name": (ctypes.c_char_p, [_i]),
     "eslam_loss_grad": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _BP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "eslam_adam_step": (_i, [_vp, _i, _i, _vp, _d, _d, _d, _i, _vp]),
 }
+
+PROF_KERNELS = 12           # ESLAM_PROF_KERNELS
+
+
+class AdamTensor(ctypes.Structure):   # eslam_adam_tensor_t
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p),
+                ("exp_avg_sq", ctypes.c_void_p), ("n", ctypes.c_int64), ("lr", ctypes.c_double)]
+
 
 _lib = None
 _lock = threading.Lock()

@@ -71,7 +71,7 @@ static bool g_ev_used[ESLAM_PROF_KERNELS];
 static const char* const g_prof_names[ESLAM_PROF_KERNELS] = {
     "render_fwd_kernel", "composite_bwd_kernel", "mlp_bwd_kernel", "dec_grad_reduce_kernel", "scatter_sort_kernel",
     "coord_bwd_kernel", "loss_reduce_kernel+loss_grad_kernel", "sample_z_kernel", "importance_z_kernel",
-    "decode_fwd_kernel"};
+    "decode_fwd_kernel", "adam_step_kernel", "keyframe_overlap_kernel"};
 
 void eslam_prof_begin(int id, hipStream_t st) {
     if (!g_prof_on) return;

@@ -133,7 +133,7 @@ __device__ __forceinline__ float4_t mfma16(float a, float b, float4_t c) {
 
 // per-kernel HIP-event timing (eslam_api.hip); PROF_* ids index eslam_profile_name()
 enum { PROF_RENDER_FWD = 0, PROF_COMPOSITE_BWD, PROF_MLP_BWD, PROF_DEC_REDUCE, PROF_SCATTER, PROF_COORD_BWD, PROF_LOSS,
-       PROF_SAMPLE_Z, PROF_IMPORTANCE_Z, PROF_DECODE_FWD };
+       PROF_SAMPLE_Z, PROF_IMPORTANCE_Z, PROF_DECODE_FWD, PROF_ADAM, PROF_KF_OVERLAP };
 void eslam_prof_begin(int id, hipStream_t st);
 void eslam_prof_end(int id, hipStream_t st);
 

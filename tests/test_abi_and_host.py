@@ -40,6 +40,7 @@ def test_struct_layout_matches_header():
     from myslam_amd import _hip
     assert ctypes.sizeof(_hip.PlaneDesc) == 8 + 8 + 4 + 4 + 3 * 8
     assert ctypes.sizeof(_hip.DecodersDesc) == 13 * 8
+    assert ctypes.sizeof(_hip.AdamTensor) == 4 * 8 + 8 + 8
     assert _hip.N_DEC_PARAMS == 2 * (16 * 64 + 16 + 16 * 16 + 16) + 17 + 51
 
 
@@ -67,6 +68,32 @@ def test_product_path_rejects_cpu_tensors():
         dec(ro, all_planes=planes)
     with pytest.raises(AttributeError):            # reference dereferences gt_depth=None (Renderer.py:91)
         r.render_batch_ray(planes, dec, ro + 1, ro, "cpu", 0.06)
+
+
+def test_adam_host_side():
+    """optim.Adam mirrors torch.optim.Adam's constructor / param_groups / state_dict (Mapper.py:291-306) and has no
+    CPU implementation."""
+    from myslam_amd import optim
+    a, b = torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5))
+    opt = optim.Adam([{"params": [a], "lr": 0}, {"params": [b], "lr": 0}])
+    ref = torch.optim.Adam([{"params": [a], "lr": 0}, {"params": [b], "lr": 0}])
+    opt.param_groups[0]["lr"] = 0.005
+    ref.param_groups[0]["lr"] = 0.005
+    keys = lambda o: {k: v for k, v in o.state_dict()["param_groups"][0].items() if k in ("lr", "betas", "eps", "weight_decay", "amsgrad", "params")}
+    assert keys(opt) == keys(ref)
+    with pytest.raises(ValueError):
+        optim.Adam([a], weight_decay=0.1)
+    with pytest.raises(ValueError):
+        optim.Adam([a], amsgrad=True)
+    with pytest.raises(ValueError):
+        optim.Adam([a], betas=(1.0, 0.999))
+    opt.step()                                   # no gradients yet: nothing to do, no GPU needed
+    assert len(opt.state) == 0
+    a.grad = torch.ones_like(a)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        opt.step()
+    opt.zero_grad()
+    assert a.grad is None
 
 
 def test_renderer_pickles():

@@ -22,8 +22,8 @@ def track():
     losses.tracking_loss(d, c, s, z, wl.gt_depth, wl.gt_color, wl.truncation).backward()
 g = harness.GraphedStep(track, [wl.rays_o, wl.rays_d])
 print(f"tracking iteration {wl.R} rays x {wl.S}: eager {timed(track):.3f} ms, graph replay {timed(g):.3f} ms")
-buf = (ctypes.c_float * 10)(); lib.eslam_profile_enable(1); track(); torch.cuda.synchronize(); lib.eslam_profile_read(buf); lib.eslam_profile_enable(0)
-print('  kernels ms:', {lib.eslam_profile_name(i).decode(): round(buf[i], 4) for i in range(10) if buf[i] >= 0})
+buf = (ctypes.c_float * 12)(); lib.eslam_profile_enable(1); track(); torch.cuda.synchronize(); lib.eslam_profile_read(buf); lib.eslam_profile_enable(0)
+print('  kernels ms:', {lib.eslam_profile_name(i).decode(): round(buf[i], 4) for i in range(12) if buf[i] >= 0})
 
 # render_img: full Replica image 680 x 1200 = 816000 rays x 40 samples, no grad
 r = wl.renderer
@@ -53,7 +53,7 @@ def f32():
         wl2.renderer.render_batch_ray(wl2.planes, wl2.decoders, wl2.rays_d, wl2.rays_o, dev, wl2.truncation, gt_depth=wl2.gt_depth, _rand=rand)
 def f16():
     lowp.render_batch_ray_lowp(wl2.renderer, wl2.planes, ph, wl2.decoders, wl2.rays_d, wl2.rays_o, wl2.truncation, wl2.gt_depth, _rand=rand)
-buf = (ctypes.c_float * 10)()
+buf = (ctypes.c_float * 12)()
 for name, fn in (('float32', f32), ('fp16 planes + bf16 MFMA', f16)):
     for _ in range(5): fn()
     ts = []

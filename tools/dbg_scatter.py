@@ -5,7 +5,7 @@ from myslam_amd import harness, _hip
 dev = torch.device('cuda:0')
 wl = harness.make_workload('room0', 4096, 56, 8, device=dev)
 lib = _hip.lib()
-buf = (ctypes.c_float * 10)()
+buf = (ctypes.c_float * 12)()
 for _ in range(3): wl.step()
 torch.cuda.synchronize()
 ts = []
