@@ -44,9 +44,13 @@ class FlatGrads:
             off += n
         self.offsets.append(off)
         self.extra = self.flat[off:]
+        self.clean = True            # all zero (fresh, or cleared by an optimiser step with fused_zero_grad)
 
     def zero_(self):
-        self.flat.zero_()
+        """Clear the buffer before a backward scatters into it - skipped when its last consumer left it zero."""
+        if not self.clean:
+            self.flat.zero_()
+        self.clean = False
 
     def all_reduce(self, group=None, async_op=False):
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
@@ -63,9 +67,14 @@ class ShardedMapper:
     step() = phase_a (sample, render forward, eslam_loss_reduce) -> all-reduce of the 16 loss accumulators ->
     phase_b (loss value, eslam_loss_grad, render backward into the flat gradient buffer) -> all-reduce of that buffer.
     The two phases contain no collective, so each can be captured into a hipGraph of its own (capture()); the two
-    all-reduces are issued eagerly between the replays - RCCL never has to run inside a captured graph."""
+    all-reduces are issued eagerly between the replays - RCCL never has to run inside a captured graph.
 
-    def __init__(self, workload, group=None):
+    optimizer: optional myslam_amd.optim.Adam over self.params (build it with make_optimizer): stepped after the
+    gradient all-reduce - every rank applies the same update to identical replicas, so they stay in sync without a
+    broadcast.  With fused_zero_grad it leaves the flat buffer zero, which saves the 27-70 MB
+    fill of the next iteration; under capture() it becomes a third graph (capturable=True is required for that)."""
+
+    def __init__(self, workload, group=None, optimizer=None):
         from . import losses
         self.wl = workload
         self.group = group
@@ -76,6 +85,7 @@ class ShardedMapper:
         if self.has_beta:
             self.params = self.params + [beta]
         self.grads = FlatGrads(self.params)
+        self.optimizer = optimizer
         self.acc = torch.zeros(16, device=workload.device)
         self._out = None
         self._graphs = None
@@ -98,12 +108,32 @@ class ShardedMapper:
                                                 self.weights, None, None, self.acc)
             self.loss.backward()
 
+    def make_optimizer(self, lrs=(0.001, 0.005, 0.005), **kw):
+        """Adam with the mapper's three groups (decoders / planes / c_planes, src/Mapper.py:296-303;
+        learning rates of configs/ESLAM.yaml:58-61 by default).  Gradients are bound to the flat buffer's views."""
+        from . import optim
+        n_dec = len(self.params) - 12
+        self.grads.assign()
+        self.optimizer = optim.Adam([{"params": self.params[12:12 + n_dec], "lr": lrs[0]},
+                                     {"params": self.params[0:6], "lr": lrs[1]},
+                                     {"params": self.params[6:12], "lr": lrs[2]}], **kw)
+        return self.optimizer
+
+    def phase_c(self):
+        """Optimiser step on the all-reduced gradients (identical on every rank)."""
+        self.grads.assign()
+        self.optimizer.step()
+        if self.optimizer.fused_zero_grad:
+            self.grads.clean = True
+
     def _eager(self):
         self.phase_a()
         dist.all_reduce(self.acc, op=dist.ReduceOp.SUM, group=self.group)
         self.phase_b()
         self.grads.all_reduce(self.group)
         self.grads.assign()
+        if self.optimizer is not None:
+            self.phase_c()
         return self.loss
 
     def capture(self, warmup=3):
@@ -120,16 +150,25 @@ class ShardedMapper:
             self.phase_a()
         with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
             self.phase_b()
+        gc = None
+        if self.optimizer is not None:
+            if not self.optimizer.capturable:
+                raise RuntimeError("capture() needs an optimiser built with capturable=True")
+            gc = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gc, pool=ga.pool(), capture_error_mode="thread_local"):
+                self.phase_c()
         torch.cuda.synchronize()
-        self._graphs = (ga, gb)
+        self._graphs = (ga, gb, gc)
 
     def step(self):
         if self._graphs is None:
             return self._eager()
-        ga, gb = self._graphs
+        ga, gb, gc = self._graphs
         ga.replay()
         dist.all_reduce(self.acc, op=dist.ReduceOp.SUM, group=self.group)
         gb.replay()
         self.grads.all_reduce(self.group)
         self.grads.assign()
+        if gc is not None:
+            gc.replay()
         return self.loss
