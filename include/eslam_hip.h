@@ -212,6 +212,17 @@ typedef struct {
 int eslam_adam_step(const eslam_adam_tensor_t* tensors_host, int n_tensors, int step, int32_t* step_dev,
                     double beta1, double beta2, double eps, int zero_grad, eslam_stream_t stream);
 
+/* Keyframe selection by view overlap, the projection test of src/Mapper.py:170-201 for all keyframes in one launch:
+ * the current frame's rays (get_samples, Mapper.py:166-168) with depth > 0 are sampled at num_samples depths between
+ * 0.8 d and d + 0.5, projected into each keyframe (w2c = inverse(c2ws[k]), x flipped, pinhole K) and counted when they
+ * fall inside the image less `edge` pixels with negative camera z.
+ *   c2ws [n_keyframes,4,4] row-major camera-to-world (the caller drops the last two keyframes, Mapper.py:183);
+ *   counts int32 [n_keyframes + 1]: counts[k] = points inside keyframe k; counts[n_keyframes] = rays with depth > 0,
+ *   so percent_inside[k] = counts[k] / (counts[n_keyframes] * num_samples)  (Mapper.py:201).                     */
+int eslam_keyframe_overlap(const float* rays_o, const float* rays_d, const float* gt_depth, int n_rays,
+                           int num_samples, const float* c2ws, int n_keyframes, int H, int W, float fx, float fy,
+                           float cx, float cy, int edge, int32_t* counts, eslam_stream_t stream);
+
 /* Per-kernel device timing for bench.py's roofline line (HIP events recorded on the launch stream around each
  * kernel while enabled; adds nothing to the launch path when disabled).  Usage: enable(1); run one iteration;
  * synchronise the stream; read(ms) -> elapsed milliseconds of the LAST launch of each kernel, -1 if it did not run. */

@@ -364,3 +364,34 @@ def tracking_loss(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, w=T
     loss = loss + w["w_color"] * ((gt_color - color) ** 2)[m].mean()
     loss = loss + w["w_depth"] * ((gt_depth[m] - depth[m]) ** 2).mean()
     return loss
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Keyframe selection by view overlap
+# ---------------------------------------------------------------------------------------------------------------
+def keyframe_overlap(rays_o, rays_d, gt_depth, keyframes_c2ws, H, W, fx, fy, cx, cy, num_samples=8, edge=20):
+    """Fraction of the current frame's sample points that project inside each keyframe's image
+    (reference src/Mapper.py:170-201).  rays_* [n,3], gt_depth [n] are get_samples' outputs for the current frame;
+    keyframes_c2ws [K,4,4] excludes the last two keyframes (Mapper.py:181).  Returns percent_inside [K] float32."""
+    keep = gt_depth > 0                                                  # Mapper.py:171-174
+    o, d, dep = rays_o[keep], rays_d[keep], gt_depth[keep].reshape(-1, 1)
+    t = torch.linspace(0., 1., steps=num_samples, dtype=dep.dtype)
+    near, far = dep * 0.8, dep + 0.5                                     # Mapper.py:177-178
+    z = near * (1. - t) + far * t
+    pts = (o[:, None, :] + d[:, None, :] * z[:, :, None]).reshape(-1, 3)
+    w2c = torch.inverse(keyframes_c2ws)                                  # Mapper.py:183
+    homo = torch.cat([pts, torch.ones_like(pts[:, :1])], -1)             # [N,4]
+    cam = torch.einsum("kij,nj->kni", w2c, homo)[:, :, :3].clone()       # [K,N,3]
+    cam[:, :, 0] *= -1                                                   # Mapper.py:192
+    Kmat = torch.tensor([[fx, .0, cx], [.0, fy, cy], [.0, .0, 1.0]], dtype=pts.dtype)
+    uv = torch.einsum("ij,knj->kni", Kmat, cam)
+    zc = uv[:, :, 2] + 1e-5
+    u, v = uv[:, :, 0] / zc, uv[:, :, 1] / zc
+    mask = (u < W - edge) & (u > edge) & (v < H - edge) & (v > edge) & (zc < 0)     # Mapper.py:196-199
+    return mask.sum(dim=1) / mask.shape[1]
+
+
+def select_overlapping(percent_inside, num_keyframes, perm):
+    """Mapper.py:203-207 with the permutation supplied: nonzero(percent) shuffled by `perm`, first num_keyframes."""
+    sel = torch.nonzero(percent_inside).squeeze(-1)
+    return [int(i) for i in sel[perm[:num_keyframes]]]

@@ -290,6 +290,49 @@ def decoder_case(ref, name="decoders_room0_points"):
     print(name, "ok")
 
 
+def keyframe_poses(K, sc, stream=700):
+    """K camera poses inside the scene: yaw angles all round the compass (so some views overlap the current frame and
+    some look away), small pitch, translation within 1 m of the AABB centre.  Shared by the fixture and the tests."""
+    out = torch.eye(4).repeat(K, 1, 1)
+    ang = synth.hash_uniform((K, 2), stream).astype(np.float64)
+    tr = synth.hash_uniform((K, 3), stream + 1).astype(np.float64)
+    for k in range(K):
+        yaw, pitch = 2 * np.pi * ang[k, 0], 0.4 * (ang[k, 1] - 0.5)
+        Ry = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]])
+        Rx = np.array([[1, 0, 0], [0, np.cos(pitch), -np.sin(pitch)], [0, np.sin(pitch), np.cos(pitch)]])
+        out[k, :3, :3] = torch.from_numpy(Ry @ Rx).float()
+        out[k, :3, 3] = sc.bound.mean(1) + torch.from_numpy(tr[k] - 0.5).float() * 2.0
+    return out
+
+
+def keyframe_overlap_case(ref, name="keyframe_overlap_room0"):
+    """Mapper.keyframe_selection_overlap (src/Mapper.py:146-209) run as an unbound method on a namespace; randperm is
+    swapped for argsort of a hash stream so that the selection order is reproducible."""
+    sc = scn.make_scene("room0")
+    K = 26                                         # the method ignores the last two (already in the window)
+    c2ws = keyframe_poses(K, sc)
+    cur = keyframe_poses(1, sc, stream=710)[0]
+    depth = torch.from_numpy(synth.depth_image(sc.H, sc.W, 720, 0.1))
+    color = torch.from_numpy(synth.color_image(sc.H, sc.W, 721))
+    ns = SimpleNamespace(device="cpu", H=sc.H, W=sc.W, fx=sc.fx, fy=sc.fy, cx=sc.cx, cy=sc.cy,
+                         estimate_c2w_list=c2ws, keyframe_list=list(range(K)))
+    real_randperm = torch.randperm
+    out = {}
+    try:
+        torch.randperm = lambda n, **kw: torch.from_numpy(np.argsort(synth.hash_uniform((n,), 730), kind="stable"))
+        for label, num in (("all", K), ("four", 4)):
+            with HashRNG(740) as rng:
+                sel = ref.Mapper.keyframe_selection_overlap(ns, color, depth, cur, num)
+            out["selected_" + label] = np.array([int(i) for i in sel], dtype=np.int64)
+            out["rand_calls"] = rng.calls_array()
+    finally:
+        torch.randperm = real_randperm
+    assert 0 < len(out["selected_all"]) < K - 2, out["selected_all"]
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), K=K, cur_c2w=cur.numpy(), c2ws=c2ws.numpy(),
+                        num_rays=50, num_samples=8, **out)
+    print(name, "ok", out["selected_all"], out["selected_four"])
+
+
 def main():
     ref = _load_reference()
     os.makedirs(OUT, exist_ok=True)
@@ -302,6 +345,8 @@ def main():
         get_samples_case(ref)
     if want("decoders"):
         decoder_case(ref)
+    if want("keyframe_overlap"):
+        keyframe_overlap_case(ref)
     # BASELINE.json configs[0]: 200 rays x 32 samples (24+8), CPU plumbing case - stored in full
     if want("room0_200x32"):
         render_case(ref, "room0_200x32", "room0", 200, 24, 8, 0.0)
