@@ -146,10 +146,13 @@ int eslam_render_bwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, c
 
 /* Decoder-only query.  Replaces src/networks/decoders.py:127-146 (Decoders.forward), the entry used by
  * src/utils/Mesher.py:151 on up to 500k points.  pts [N,3] world coordinates -> raw [N,4] = (r,g,b,sdf).
- * sdf_only != 0 evaluates geometry planes + SDF decoder only (decoders.py:87-105) and writes raw [N,1].
- * feat [N,128] optional (needed only for eslam_decode_bwd).                                          */
+ * flags: ESLAM_DECODE_SDF_ONLY evaluates geometry planes + SDF decoder only (decoders.py:87-105) and writes
+ * raw [N,1]; ESLAM_DECODE_MASK_OUTSIDE sets the sdf of every point that is not strictly inside the bound to -1
+ * (Mesher.eval_points, src/utils/Mesher.py:146-153).  feat [N,128] optional (needed only for eslam_decode_bwd). */
+#define ESLAM_DECODE_SDF_ONLY 1
+#define ESLAM_DECODE_MASK_OUTSIDE 2
 int eslam_decode_fwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
-                     const float* pts, int64_t N, int sdf_only, float* raw, float* feat, eslam_stream_t stream);
+                     const float* pts, int64_t N, int flags, float* raw, float* feat, eslam_stream_t stream);
 
 /* Backward of eslam_decode_fwd: g_raw [N,4] upstream, raw [N,4] the forward output.  Same gradient outputs as
  * eslam_render_bwd, with g_pts [N,3] (may be NULL) instead of ray gradients.                          */

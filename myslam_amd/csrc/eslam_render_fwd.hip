@@ -118,7 +118,8 @@ __global__ __launch_bounds__(256, FWD_WAVES) void render_fwd_kernel(const PlaneS
 template <bool CL, bool SDF_ONLY, bool SAVE>
 __global__ __launch_bounds__(256, FWD_WAVES) void decode_fwd_kernel(const PlaneSet planes, const eslam_decoders_t dec,
                                                          const Bound bnd, const float* __restrict__ pts, int64_t N,
-                                                         float* __restrict__ raw, float* __restrict__ feat_out) {
+                                                         float* __restrict__ raw, float* __restrict__ feat_out,
+                                                         const int mask_outside) {
     __shared__ __attribute__((aligned(16))) float wlds[2 * DEC_LDS];
     stage_decoder_weights(wlds, dec, threadIdx.x, blockDim.x);
     __syncthreads();
@@ -157,7 +158,13 @@ __global__ __launch_bounds__(256, FWD_WAVES) void decode_fwd_kernel(const PlaneS
             }
         }
         if (lane < nvalid) {
-            const float sdf = tanhf(out[0][0]);
+            float sdf = tanhf(out[0][0]);
+            if (mask_outside) {     // Mesher.eval_points (Mesher.py:146-153): points not strictly inside the bound get -1
+                const float* pp = pts + (p0 + lane) * 3;
+                const bool in = pp[0] < bnd.hi[0] && pp[0] > bnd.lo[0] && pp[1] < bnd.hi[1] && pp[1] > bnd.lo[1] &&
+                                pp[2] < bnd.hi[2] && pp[2] > bnd.lo[2];
+                if (!in) sdf = -1.0f;
+            }
             if (SDF_ONLY) {
                 raw[p0 + lane] = sdf;
             } else {
@@ -226,9 +233,15 @@ extern "C" int eslam_render_fwd(const eslam_plane_t* planes, const eslam_decoder
 }
 
 extern "C" int eslam_decode_fwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
-                                const float* pts, int64_t N, int sdf_only, float* raw, float* feat,
+                                const float* pts, int64_t N, int flags, float* raw, float* feat,
                                 eslam_stream_t stream) {
     if (N <= 0) return 0;
+    if (flags & ~(ESLAM_DECODE_SDF_ONLY | ESLAM_DECODE_MASK_OUTSIDE)) {
+        eslam_set_error("eslam_decode_fwd: unknown flags 0x%x", flags);
+        return 1;
+    }
+    const int sdf_only = flags & ESLAM_DECODE_SDF_ONLY;
+    const int mask_outside = (flags & ESLAM_DECODE_MASK_OUTSIDE) ? 1 : 0;
     if (!planes || !dec || !bound6_host || !pts || !raw) {
         eslam_set_error("eslam_decode_fwd: null argument");
         return 1;
@@ -247,7 +260,8 @@ extern "C" int eslam_decode_fwd(const eslam_plane_t* planes, const eslam_decoder
     dim3 grid((unsigned)(nwg < 8192 ? nwg : 8192)), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(CLv, SO, SV) \
-    hipLaunchKernelGGL((decode_fwd_kernel<CLv, SO, SV>), grid, block, 0, st, ps, *dec, bnd, pts, N, raw, feat)
+    hipLaunchKernelGGL((decode_fwd_kernel<CLv, SO, SV>), grid, block, 0, st, ps, *dec, bnd, pts, N, raw, feat, \
+                       mask_outside)
     eslam_prof_begin(PROF_DECODE_FWD, st);
     if (sdf_only) {
         if (cl) LAUNCH(true, true, false);

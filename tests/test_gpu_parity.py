@@ -346,6 +346,38 @@ def test_sharded_mapper_one_rank_rccl():
         dist.destroy_process_group()
 
 
+def test_mesher_eval_points_against_oracle():
+    """Mesher.eval_points (src/utils/Mesher.py:130-157): batches of the marching-cubes grid through the decoders, sdf
+    = -1 for points not strictly inside the bound.  Grid straddles the bound, ragged last batch."""
+    from oracle import eslam_oracle as orc
+    from myslam_amd import harness
+    from myslam_amd.src.utils.Mesher import eval_points
+    dev = _dev()
+    wl = harness.make_workload("room0", 64, 24, 8, device=dev, planes="synth")
+    b = wl.scene.bound
+    axes = [torch.linspace(float(b[k, 0]) - 0.3, float(b[k, 1]) + 0.3, n) for k, n in enumerate((41, 33, 29))]
+    axes[0][5] = b[0, 0]
+    axes[1][-4] = b[1, 1]                                  # points exactly on a face are outside (strict test)
+    pts = torch.stack(torch.meshgrid(*axes, indexing="ij"), -1).reshape(-1, 3)
+    mesher = SimpleNamespace(points_batch_size=10000, bound=b)
+    got = eval_points(mesher, pts.to(dev), wl.planes, wl.decoders).cpu()
+    cparams = {k: v.detach().cpu() for k, v in wl.decoders.state_dict().items() if k != "beta"}
+    cplanes = tuple([p.detach().cpu().contiguous() for p in grp] for grp in wl.planes)
+    ref = orc.decode(pts, cplanes, cparams, b)
+    inside = ((pts < b[:, 1]) & (pts > b[:, 0])).all(dim=1)
+    assert 0.2 < float(inside.float().mean()) < 0.9
+    ref[~inside, -1] = -1
+    assert got.shape == (pts.shape[0], 4)
+    assert torch.equal(got[~inside, 3], torch.full((int((~inside).sum()),), -1.0))
+    assert hp.rel_err(got.numpy(), ref.numpy()) <= RTOL
+    # a mesher bound different from the decoders' falls back to masking with the mesher's own bound
+    mesher2 = SimpleNamespace(points_batch_size=7777, bound=b * 0.5)
+    got2 = eval_points(mesher2, pts.to(dev), wl.planes, wl.decoders).cpu()
+    inside2 = ((pts < b[:, 1] * 0.5) & (pts > b[:, 0] * 0.5)).all(dim=1)
+    assert torch.equal(got2[~inside2, 3], torch.full((int((~inside2).sum()),), -1.0))
+    assert hp.rel_err(got2[inside2].numpy(), ref[inside2].numpy()) <= RTOL
+
+
 def test_graft_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
