@@ -54,6 +54,14 @@ _SCENES = {
         n_stratified=48, n_importance=8, learnable_beta=False,
         mapping_pixels=5000, tracking_pixels=5000, ignore_edge=20,
     ),
+    # NOT a reference scene: a 4 x 3 x 2.4 m synthetic room with a 240 x 320 camera for the end-to-end quality runs
+    # (myslam_amd/synthscene.py, tests/test_gpu_slam_quality.py); planes total ~2.3 MB so the CPU oracle can keep up
+    "toy": dict(
+        bound=[[-2.0, 2.0], [-1.5, 1.5], [-1.2, 1.2]],
+        cam=dict(H=240, W=320, fx=160.0, fy=160.0, cx=159.5, cy=119.5, crop_edge=0),
+        n_stratified=32, n_importance=8, learnable_beta=True,
+        mapping_pixels=1000, tracking_pixels=500, ignore_edge=10,
+    ),
 }
 
 PLANE_NAMES = ("planes_xy", "planes_xz", "planes_yz", "c_planes_xy", "c_planes_xz", "c_planes_yz")

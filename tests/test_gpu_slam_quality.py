@@ -1,0 +1,63 @@
+"""End-to-end quality at equal iterations (SURVEY.md section 8(d) "Quality"; BASELINE.json configs[2] in miniature):
+the tracking + mapping loop of myslam_amd/slam.py over the analytic RGB-D sequence of myslam_amd/synthscene.py, once
+on the HIP path (GPU) and once on the CPU oracle (the reference's arithmetic), same frames, same iteration counts,
+same initial planes and decoders.  The two runs draw different random pixels / jitter (GPU vs CPU generators), so
+the comparison is statistical: trajectory error (ATE RMSE after Horn alignment), colour PSNR and depth L1 of a
+rendered held-out view must agree within the stated bands, and both must be good in absolute terms."""
+import os
+import time
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(backend_kind, n_frames, cfg, seed=0):
+    from myslam_amd import eval_ate, scene as scn, slam, synthscene
+    sc = scn.make_scene("toy")
+    if backend_kind == "hip":
+        dev, backend = torch.device("cuda:0"), None
+    else:
+        from tests.oracle_backend import OracleBackend
+        dev, backend = torch.device("cpu"), OracleBackend(sc)
+    frames = synthscene.make_sequence(sc, n_frames, device=dev)
+    torch.manual_seed(seed)
+    t0 = time.perf_counter()
+    s = slam.Slam(sc, cfg, device=dev, backend=backend, seed=seed)
+    est = s.run(frames)
+    s.stats["loop_seconds"] = round(time.perf_counter() - t0, 2)
+    ate = eval_ate.evaluate([e.cpu().numpy() for e in est], [f[3].cpu().numpy() for f in frames])
+    # held-out view: a pose half-way between two mapped keyframes, rendered from the analytic scene
+    room = synthscene.AnalyticRoom(sc.bound)
+    pose = synthscene.trajectory(2 * n_frames, sc.bound, yaw_step_deg=0.75)[9].to(dev)
+    gd, gc = synthscene.render_frame(room, sc, pose, dev)
+    q = s.render_quality(gc, gd, pose)
+    return ate, q, s.stats
+
+
+def test_tracking_mapping_loop_quality_matches_oracle_loop(monkeypatch):
+    from myslam_amd import slam
+    from oracle import eslam_oracle as orc
+    monkeypatch.setattr(orc, "BILINEAR_IMPL", "grid_sample")      # the op the reference calls; faster on the CPU
+    cfg = slam.SlamConfig(tracking_pixels=500, tracking_iters=8, ignore_edge_H=10, ignore_edge_W=10, mapping_pixels=1000,
+                          iters_first=100, iters=10, every_frame=4, keyframe_every=4)
+    n_frames = 13
+    ate_h, q_h, st_h = _run("hip", n_frames, cfg)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))      # the box reports far more cores than it grants
+    try:
+        ate_o, q_o, st_o = _run("oracle", n_frames, cfg)
+    finally:
+        torch.set_num_threads(threads)
+    print(f"\nHIP    loop: ATE rmse {ate_h['rmse']*100:.2f} cm, PSNR {q_h['psnr']:.2f} dB, depth L1 {q_h['depth_l1']*100:.2f} cm, {st_h}")
+    print(f"oracle loop: ATE rmse {ate_o['rmse']*100:.2f} cm, PSNR {q_o['psnr']:.2f} dB, depth L1 {q_o['depth_l1']*100:.2f} cm, {st_o}")
+    assert st_h["tracking_iters"] == st_o["tracking_iters"] == 8 * (n_frames - 1)
+    assert st_h["mapping_iters"] == st_o["mapping_iters"] == 100 + 10 * 3
+    # absolute quality (the camera moves ~4.5 cm and 1.5 degrees per frame)
+    assert ate_h["rmse"] < 0.02 and ate_o["rmse"] < 0.02
+    assert q_h["psnr"] > 18.0 and q_h["depth_l1"] < 0.05
+    # agreement of the two paths
+    assert abs(q_h["psnr"] - q_o["psnr"]) < 1.0
+    assert abs(q_h["depth_l1"] - q_o["depth_l1"]) < 0.3 * max(q_h["depth_l1"], q_o["depth_l1"]) + 0.002
+    assert abs(ate_h["rmse"] - ate_o["rmse"]) < 0.5 * max(ate_h["rmse"], ate_o["rmse"]) + 0.002
