@@ -163,9 +163,12 @@ int eslam_decode_bwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, c
 /* Caller-side loss of one optimisation iteration, value and upstream gradients in two small launches and
  * without the boolean-mask host syncs of the PyTorch formulation.  Replaces src/Mapper.py:110-144 (sdf_losses)
  * + :337-346, and src/Tracker.py:114-148 + :197-204 when ray_mask is given.
- *   ray_mask == NULL (mapping): SDF and depth terms over rays with gt_depth > 0, colour term over all rays.
- *   ray_mask != NULL (tracking): uint8 [R], the 10x-median outlier mask of Tracker.py:193-195 computed by the
- *                                caller; SDF, depth and colour terms all run over the masked rays.
+ *   ray_mask == NULL: every ray belongs to the batch.
+ *   ray_mask != NULL: uint8 [R], the rays that belong to the batch - the 10x-median outlier mask of
+ *                     Tracker.py:193-195, and/or the AABB pre-filter of Mapper.py:322-332 / Tracker.py:175-187 kept
+ *                     as a mask instead of a compaction (no host sync, static shapes for hipGraph capture).
+ *   Colour term: mean over the batch's rays; SDF and depth terms: mean over the batch's rays with gt_depth > 0
+ *   (in tracking the pre-filter already requires depth, so all three run over the same rays, as the reference's do).
  * weights5_host = {w_sdf_fs, w_sdf_center, w_sdf_tail, w_depth, w_color}  (configs/ESLAM.yaml:29-33,53-57).
  * Outputs: loss [1]; g_depth [R], g_rgb [R,3], g_sdf [R,S] = d loss / d (depth, rgb, sdf) (overwritten).
  * Means over empty sets give NaN exactly as torch.mean does.  scratch: 64 bytes, any contents.            */

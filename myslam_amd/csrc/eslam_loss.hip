@@ -38,8 +38,8 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restric
     for (int k = 0; k < A_COUNT; ++k) v[k] = 0.0f;
     for (int ray = blockIdx.x * 4 + wave; ray < R; ray += gridDim.x * 4) {
         const float d = gt_depth[ray];
-        const bool m = ray_mask ? (ray_mask[ray] != 0) : (d > 0.0f);
-        const bool mc = ray_mask ? m : true;
+        const bool mc = ray_mask ? (ray_mask[ray] != 0) : true;      // rays of the batch (colour term)
+        const bool m = mc && d > 0.0f;                                // ... that have depth (SDF and depth terms)
         if (m) {
             for (int s = lane; s < S; s += WAVE) {
                 const float z = z_vals[(int64_t)ray * S + s];
@@ -90,8 +90,8 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
         w.fs *= u; w.center *= u; w.tail *= u; w.depth *= u; w.color *= u;
     }
     const float d = gt_depth[ray];
-    const bool m = ray_mask ? (ray_mask[ray] != 0) : (d > 0.0f);
-    const bool mc = ray_mask ? m : true;
+    const bool mc = ray_mask ? (ray_mask[ray] != 0) : true;
+    const bool m = mc && d > 0.0f;
     const float kf = 2.0f * w.fs / nf, kc = 2.0f * w.center * tr.t / nc, kt = 2.0f * w.tail * tr.t / nt;
     for (int s = lane; s < S; s += WAVE) {
         float g = 0.0f;

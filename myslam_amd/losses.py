@@ -12,13 +12,23 @@ MAPPING_W = (5.0, 200.0, 10.0, 0.1, 5.0)       # w_sdf_fs, w_sdf_center, w_sdf_t
 TRACKING_W = (10.0, 200.0, 50.0, 1.0, 5.0)
 
 
-def mapping_loss(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights=MAPPING_W):
-    """Mapper.py:337-346: SDF + depth terms over rays with gt_depth > 0, colour over all rays."""
-    return ops.MappingLossFn.apply(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights, None, None, None)
+def mapping_loss(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights=MAPPING_W, ray_mask=None):
+    """Mapper.py:337-346: SDF + depth terms over rays with gt_depth > 0, colour over all rays.
+    ray_mask (bool [R], optional): restrict every term to these rays - the AABB pre-filter of Mapper.py:322-332 kept
+    as a mask, so the batch keeps a static shape and no boolean index forces a host sync."""
+    return ops.MappingLossFn.apply(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights, ray_mask, None,
+                                   None)
 
 
-def tracking_loss(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights=TRACKING_W):
-    """Tracker.py:192-204: all terms over the rays whose depth error is below 10x the median error."""
+def tracking_loss(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights=TRACKING_W, ray_mask=None):
+    """Tracker.py:192-204: all terms over the rays whose depth error is below 10x the median error.
+    ray_mask (bool [R], optional): the pre-filter of Tracker.py:175-187 (inside the bound and depth > 0) as a mask;
+    the median is then taken over the masked rays only, without a host sync (lower median, as torch.median)."""
     err = (gt_depth - depth.detach()).abs()
-    mask = err < 10 * err.median()
+    if ray_mask is None:
+        mask = err < 10 * err.median()
+    else:
+        srt = torch.where(ray_mask, err, torch.full_like(err, float("inf"))).sort().values
+        k = ((ray_mask.sum() - 1).clamp(min=0) // 2).reshape(1)
+        mask = ray_mask & (err < 10 * srt.gather(0, k))
     return ops.MappingLossFn.apply(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights, mask, None, None)

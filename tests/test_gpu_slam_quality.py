@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 def _run(backend_kind, n_frames, cfg, seed=0):
     from myslam_amd import eval_ate, scene as scn, slam, synthscene
     sc = scn.make_scene("toy")
-    if backend_kind == "hip":
+    if backend_kind in ("hip", "graph"):
         dev, backend = torch.device("cuda:0"), None
     else:
         from tests.oracle_backend import OracleBackend
@@ -24,7 +24,11 @@ def _run(backend_kind, n_frames, cfg, seed=0):
     frames = synthscene.make_sequence(sc, n_frames, device=dev)
     torch.manual_seed(seed)
     t0 = time.perf_counter()
-    s = slam.Slam(sc, cfg, device=dev, backend=backend, seed=seed)
+    if backend_kind == "graph":
+        from myslam_amd.slam_graph import GraphedSlam
+        s = GraphedSlam(sc, cfg, device=dev, seed=seed)
+    else:
+        s = slam.Slam(sc, cfg, device=dev, backend=backend, seed=seed)
     est = s.run(frames)
     s.stats["loop_seconds"] = round(time.perf_counter() - t0, 2)
     ate = eval_ate.evaluate([e.cpu().numpy() for e in est], [f[3].cpu().numpy() for f in frames])
@@ -61,3 +65,21 @@ def test_tracking_mapping_loop_quality_matches_oracle_loop(monkeypatch):
     assert abs(q_h["psnr"] - q_o["psnr"]) < 1.0
     assert abs(q_h["depth_l1"] - q_o["depth_l1"]) < 0.3 * max(q_h["depth_l1"], q_o["depth_l1"]) + 0.002
     assert abs(ate_h["rmse"] - ate_o["rmse"]) < 0.5 * max(ate_h["rmse"], ate_o["rmse"]) + 0.002
+
+
+def test_graph_captured_loop_matches_eager_loop():
+    """slam_graph.GraphedSlam (every iteration a replayed hipGraph; pre-filters as masks, device-side median / best-pose
+    select, fused Adam with a device step counter) against the eager loop on the same sequence."""
+    from myslam_amd import slam
+    cfg = slam.SlamConfig(tracking_pixels=500, tracking_iters=8, ignore_edge_H=10, ignore_edge_W=10, mapping_pixels=1000,
+                          iters_first=100, iters=10, every_frame=4, keyframe_every=4)
+    n_frames = 25                                   # 7 mapped frames: window sizes 1, 1, 3, 4, ..., joint_opt from the 6th
+    ate_e, q_e, st_e = _run("hip", n_frames, cfg)
+    ate_g, q_g, st_g = _run("graph", n_frames, cfg)
+    print(f"\neager loop: ATE rmse {ate_e['rmse']*100:.2f} cm, PSNR {q_e['psnr']:.2f} dB, depth L1 {q_e['depth_l1']*100:.2f} cm, {st_e}")
+    print(f"graph loop: ATE rmse {ate_g['rmse']*100:.2f} cm, PSNR {q_g['psnr']:.2f} dB, depth L1 {q_g['depth_l1']*100:.2f} cm, {st_g}")
+    assert st_g["tracking_iters"] == st_e["tracking_iters"] and st_g["mapping_iters"] == st_e["mapping_iters"]
+    assert ate_g["rmse"] < 0.02 and q_g["psnr"] > 18.0 and q_g["depth_l1"] < 0.05
+    assert abs(q_g["psnr"] - q_e["psnr"]) < 1.0
+    assert abs(q_g["depth_l1"] - q_e["depth_l1"]) < 0.3 * max(q_g["depth_l1"], q_e["depth_l1"]) + 0.002
+    assert abs(ate_g["rmse"] - ate_e["rmse"]) < 0.5 * max(ate_g["rmse"], ate_e["rmse"]) + 0.002

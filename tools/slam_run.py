@@ -1,7 +1,7 @@
 """BASELINE.json configs[2] in synthetic form: the tracking + mapping loop (myslam_amd/slam.py) on the HIP path over an
 analytic RGB-D sequence in the Replica room0 geometry (680 x 1200 images, room0 bound and planes, the reference's
 Replica iteration counts and pixel budgets), reporting ATE, render quality and where the time goes.
-    python tools/slam_run.py [n_frames] [iters_first]
+    python tools/slam_run.py [n_frames] [iters_first] [eager|graph]
 """
 import sys, time, torch
 sys.path.insert(0, '.')
@@ -9,6 +9,7 @@ from myslam_amd import eval_ate, scene as scn, slam, synthscene
 
 n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 41
 iters_first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+mode = sys.argv[3] if len(sys.argv) > 3 else 'eager'
 dev = torch.device('cuda:0')
 sc = scn.make_scene('room0')
 cfg = slam.SlamConfig(iters_first=iters_first)          # configs/ESLAM.yaml + configs/Replica/replica.yaml values
@@ -17,7 +18,11 @@ frames = synthscene.make_sequence(sc, n_frames, device=dev)
 torch.cuda.synchronize()
 print(f"sequence of {n_frames} frames {sc.H}x{sc.W} rendered in {time.perf_counter()-t0:.1f} s", flush=True)
 torch.manual_seed(0)
-s = slam.Slam(sc, cfg, device=dev, seed=0)
+if mode == 'graph':
+    from myslam_amd.slam_graph import GraphedSlam
+    s = GraphedSlam(sc, cfg, device=dev, seed=0)
+else:
+    s = slam.Slam(sc, cfg, device=dev, seed=0)
 marks = []
 def on_frame(s_, i):
     torch.cuda.synchronize()
@@ -37,7 +42,7 @@ q = s.render_quality(gc, gd, pose)
 st = s.stats
 first = marks[0] - t1
 print(f"ATE rmse {ate['rmse']*100:.2f} cm (mean {ate['mean']*100:.2f}, max {ate['max']*100:.2f}); held-out view PSNR {q['psnr']:.2f} dB, depth L1 {q['depth_l1']*100:.2f} cm")
-print(f"loop {total:.1f} s: first-frame mapping ({iters_first} iterations) {first:.1f} s = {first/iters_first*1e3:.2f} ms/iteration; "
+print(f"[{mode}] loop {total:.1f} s: first-frame mapping ({iters_first} iterations) {first:.1f} s = {first/iters_first*1e3:.2f} ms/iteration; "
       f"remaining {n_frames-1} frames {total-first:.1f} s = {(n_frames-1)/(total-first):.1f} frames/s "
       f"({st['tracking_iters']} tracking + {st['mapping_iters']-iters_first} mapping iterations, "
-      f"{(total-first)/(st['tracking_iters']+st['mapping_iters']-iters_first)*1e3:.2f} ms/iteration eager)")
+      f"{(total-first)/(st['tracking_iters']+st['mapping_iters']-iters_first)*1e3:.2f} ms/iteration)")
