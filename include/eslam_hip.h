@@ -229,6 +229,28 @@ int eslam_keyframe_overlap(const float* rays_o, const float* rays_d, const float
                            int num_samples, const float* c2ws, int n_keyframes, int H, int W, float fx, float fy,
                            float cx, float cy, int edge, int32_t* counts, eslam_stream_t stream);
 
+/* Caller-side glue of the optimisation loops, one launch each instead of a chain of small tensor ops.
+ *
+ * eslam_prefilter: keep[i] = (AABB exit distance of ray i >= gt_depth[i]) [&& gt_depth[i] > 0 when need_depth]
+ *   - the pre-filter of src/Mapper.py:322-328 (need_depth = 0) and src/Tracker.py:175-182 (need_depth = 1) as a uint8
+ *   mask for the `ray_mask` of the loss entry points, instead of a boolean-index compaction.
+ * eslam_pose_to_c2w(_bwd): src/common.py:169-181 cam_pose_to_matrix - poses [b,7] = (quaternion real-first, translation)
+ *   -> c2ws [b,4,4] with R = quaternion_to_matrix(q) (q need not be normalised: two_s = 2 / |q|^2) - and its
+ *   backward g_c2ws [b,4,4] -> g_poses [b,7].
+ * eslam_tracking_mask: src/Tracker.py:192-195.  mask[i] = keep[i] && |gt_depth[i] - depth[i]| < factor * median, the
+ *   (lower, as torch.median) median taken over the rays with keep[i] != 0 (all rays when keep is NULL); R <=
+ *   ESLAM_TRACKING_MASK_MAX.  A NaN error makes the median NaN and the mask empty, as in the reference.
+ * eslam_keep_best: src/Tracker.py:304-307.  if (loss[0] < best[0]) { best[0] = loss[0]; best_pose[0..n) = pose[0..n); } */
+#define ESLAM_TRACKING_MASK_MAX 8192
+int eslam_prefilter(const float* rays_o, const float* rays_d, const float* gt_depth, int R, const float* bound6_host,
+                    int need_depth, uint8_t* keep, eslam_stream_t stream);
+int eslam_pose_to_c2w(const float* poses, int b, float* c2ws, eslam_stream_t stream);
+int eslam_pose_to_c2w_bwd(const float* poses, const float* g_c2ws, int b, float* g_poses, eslam_stream_t stream);
+int eslam_tracking_mask(const float* depth, const float* gt_depth, const uint8_t* keep, int R, float factor,
+                        uint8_t* mask, eslam_stream_t stream);
+int eslam_keep_best(const float* loss, const float* pose, int n, float* best, float* best_pose,
+                    eslam_stream_t stream);
+
 /* Per-kernel device timing for bench.py's roofline line (HIP events recorded on the launch stream around each
  * kernel while enabled; adds nothing to the launch path when disabled).  Usage: enable(1); run one iteration;
  * synchronise the stream; read(ms) -> elapsed milliseconds of the LAST launch of each kernel, -1 if it did not run. */

@@ -60,6 +60,11 @@ SIGNATURES = {
     "eslam_profile_name": (ctypes.c_char_p, [_i]),
     "eslam_loss_grad": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _BP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "eslam_adam_step": (_i, [_vp, _i, _i, _vp, _d, _d, _d, _i, _vp]),
+    "eslam_prefilter": (_i, [_vp, _vp, _vp, _i, _BP, _i, _vp, _vp]),
+    "eslam_pose_to_c2w": (_i, [_vp, _i, _vp, _vp]),
+    "eslam_pose_to_c2w_bwd": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "eslam_tracking_mask": (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp]),
+    "eslam_keep_best": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "eslam_keyframe_overlap": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _f, _f, _f, _f, _i, _vp, _vp]),
 }
 

@@ -140,6 +140,20 @@ __global__ void aabb_exit_kernel(const float* __restrict__ rays_o, const float* 
     t_exit[i] = aabb_exit_dev(o, d, bnd);
 }
 
+// the callers' pre-filter as a mask: keep = (t_exit >= gt_depth) [& (gt_depth > 0)]   (Mapper.py:322-328, Tracker.py:175-182)
+__global__ void prefilter_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                 const float* __restrict__ gt_depth, int R, const Bound bnd, int need_depth,
+                                 uint8_t* __restrict__ keep) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    const float o[3] = {rays_o[3 * i], rays_o[3 * i + 1], rays_o[3 * i + 2]};
+    const float d[3] = {rays_d[3 * i], rays_d[3 * i + 1], rays_d[3 * i + 2]};
+    const float gd = gt_depth[i];
+    bool k = aabb_exit_dev(o, d, bnd) >= gd;                 // false for NaN, as the tensor comparison
+    if (need_depth) k = k && gd > 0.0f;
+    keep[i] = k ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // K3: reference src/utils/Renderer.py:85-105 and :46-61
 // One wave per ray.  The two sequences are ascending, so the "sort" of Renderer.py:102 is a rank merge:
@@ -390,6 +404,18 @@ extern "C" int eslam_aabb_exit(const float* rays_o, const float* rays_d, int R, 
     hipLaunchKernelGGL(aabb_exit_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d, R,
                        make_bound(bound6_host), t_exit);
     return eslam_check_launch("aabb_exit_kernel");
+}
+
+extern "C" int eslam_prefilter(const float* rays_o, const float* rays_d, const float* gt_depth, int R,
+                               const float* bound6_host, int need_depth, uint8_t* keep, eslam_stream_t stream) {
+    if (R <= 0) return 0;
+    if (!rays_o || !rays_d || !gt_depth || !bound6_host || !keep) {
+        eslam_set_error("eslam_prefilter: null argument");
+        return 1;
+    }
+    hipLaunchKernelGGL(prefilter_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d,
+                       gt_depth, R, make_bound(bound6_host), need_depth, keep);
+    return eslam_check_launch("prefilter_kernel");
 }
 
 extern "C" int eslam_sample_z(const float* gt_depth, int R, int n_strat, int n_imp, double truncation,

@@ -24,11 +24,14 @@ def tracking_loss(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, wei
     """Tracker.py:192-204: all terms over the rays whose depth error is below 10x the median error.
     ray_mask (bool [R], optional): the pre-filter of Tracker.py:175-187 (inside the bound and depth > 0) as a mask;
     the median is then taken over the masked rays only, without a host sync (lower median, as torch.median)."""
-    err = (gt_depth - depth.detach()).abs()
-    if ray_mask is None:
-        mask = err < 10 * err.median()
+    if depth.is_cuda and depth.shape[0] <= ops.TRACKING_MASK_MAX:
+        mask = ops.tracking_mask(depth, gt_depth, ray_mask)                 # one launch, no host sync
     else:
-        srt = torch.where(ray_mask, err, torch.full_like(err, float("inf"))).sort().values
-        k = ((ray_mask.sum() - 1).clamp(min=0) // 2).reshape(1)
-        mask = ray_mask & (err < 10 * srt.gather(0, k))
+        err = (gt_depth - depth.detach()).abs()
+        if ray_mask is None:
+            mask = err < 10 * err.median()
+        else:
+            srt = torch.where(ray_mask, err, torch.full_like(err, float("inf"))).sort().values
+            k = ((ray_mask.sum() - 1).clamp(min=0) // 2).reshape(1)
+            mask = ray_mask & (err < 10 * srt.gather(0, k))
     return ops.MappingLossFn.apply(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights, mask, None, None)

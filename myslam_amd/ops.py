@@ -362,6 +362,71 @@ def aabb_exit(rays_o, rays_d, bound6):
     return t
 
 
+def prefilter(rays_o, rays_d, gt_depth, bound6, need_depth):
+    """bool [R]: the callers' AABB (+ depth) pre-filter as a mask (Mapper.py:322-328 / Tracker.py:175-182), one launch."""
+    _hip.require_gpu_f32("rays_o", rays_o)
+    ro, rd, gd = _c(rays_o.detach()), _c(rays_d.detach()), _c(gt_depth)
+    R = ro.shape[0]
+    keep = torch.empty(R, dtype=torch.uint8, device=ro.device)
+    with _hip.on_device(ro.device):
+        _hip.check(_hip.lib().eslam_prefilter(_hip.ptr(ro), _hip.ptr(rd), _hip.ptr(gd), R, _hip.make_bound(bound6),
+                                              1 if need_depth else 0, _hip.ptr(keep), _hip.stream_handle(ro.device)),
+                   "eslam_prefilter")
+    return keep.view(torch.bool)
+
+
+TRACKING_MASK_MAX = 8192        # ESLAM_TRACKING_MASK_MAX
+
+
+def tracking_mask(depth, gt_depth, keep=None, factor=10.0):
+    """bool [R]: Tracker.py:192-195, |gt_depth - depth| < factor * median over the kept rays, one launch."""
+    _hip.require_gpu_f32("depth", depth)
+    d, gd = _c(depth.detach()), _c(gt_depth)
+    R = d.shape[0]
+    if keep is not None:
+        keep = _c(keep.view(torch.uint8) if keep.dtype == torch.bool else keep.to(torch.uint8))
+    mask = torch.empty(R, dtype=torch.uint8, device=d.device)
+    with _hip.on_device(d.device):
+        _hip.check(_hip.lib().eslam_tracking_mask(_hip.ptr(d), _hip.ptr(gd), _hip.ptr(keep), R, float(factor),
+                                                  _hip.ptr(mask), _hip.stream_handle(d.device)), "eslam_tracking_mask")
+    return mask.view(torch.bool)
+
+
+def keep_best(loss, pose, best, best_pose):
+    """In place: if loss < best, best = loss and best_pose = pose (Tracker.py:304-307), without a host round trip."""
+    _hip.require_gpu_f32("loss", loss)
+    pose = _c(pose.detach())
+    with _hip.on_device(loss.device):
+        _hip.check(_hip.lib().eslam_keep_best(_hip.ptr(loss.detach()), _hip.ptr(pose), pose.numel(), _hip.ptr(best),
+                                              _hip.ptr(best_pose), _hip.stream_handle(loss.device)), "eslam_keep_best")
+
+
+class PoseToMatrixFn(torch.autograd.Function):
+    """c2ws [b,4,4] = PoseToMatrixFn.apply(poses [b,7])   (common.py:169-181, quaternion real-first then translation)"""
+
+    @staticmethod
+    def forward(ctx, poses):
+        _hip.require_gpu_f32("batch_poses", poses)
+        p = _c(poses.detach())
+        b = p.shape[0]
+        out = torch.empty(b, 4, 4, device=p.device)
+        with _hip.on_device(p.device):
+            _hip.check(_hip.lib().eslam_pose_to_c2w(_hip.ptr(p), b, _hip.ptr(out), _hip.stream_handle(p.device)),
+                       "eslam_pose_to_c2w")
+        ctx.save_for_backward(p)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (p,) = ctx.saved_tensors
+        g = _c(g)
+        gp = torch.empty_like(p)
+        with _hip.on_device(p.device):
+            _hip.check(_hip.lib().eslam_pose_to_c2w_bwd(_hip.ptr(p), _hip.ptr(g), p.shape[0], _hip.ptr(gp),
+                                                        _hip.stream_handle(p.device)), "eslam_pose_to_c2w_bwd")
+        return gp
+
+
 def sample_z(rays_o, rays_d, gt_depth, all_planes, decoders, bound6, truncation, n_strat, n_imp, perturb,
              rand=None):
     """z_vals [R,S] of reference Renderer.py:85-134, sync-free: both samplers run over all rays and each skips
@@ -430,7 +495,7 @@ class MappingLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, depth, rgb, sdf, z_vals, gt_depth, gt_color, truncation, weights5, ray_mask, group, acc):
         if ray_mask is not None:
-            ray_mask = _c(ray_mask.to(torch.uint8))
+            ray_mask = _c(ray_mask.view(torch.uint8) if ray_mask.dtype == torch.bool else ray_mask.to(torch.uint8))
         if acc is None:
             acc = loss_reduce(depth, rgb, sdf, z_vals, gt_depth, gt_color, truncation, ray_mask)
             if group is not None:

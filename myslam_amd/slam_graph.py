@@ -17,11 +17,12 @@ poses and camera parameters live in static buffers that are overwritten between 
 still change every replay (torch's graph-safe Philox generator).  Same arithmetic per kept ray as slam.Slam; the
 random streams differ (all rays draw jitter, not only the kept ones), so results agree statistically, not bitwise.
 """
+import time
 from types import SimpleNamespace
 
 import torch
 
-from . import losses, optim
+from . import losses, ops, optim
 from .slam import HipBackend, Slam
 
 
@@ -29,6 +30,7 @@ class GraphedSlam(Slam):
     def __init__(self, sc, cfg=None, device="cuda:0", seed=0, warmup=2):
         super().__init__(sc, cfg, device, backend=HipBackend(sc, device), seed=seed)
         self.warmup = warmup
+        self._bound6 = ops.bound_to_host(sc.bound)
         # persistent Parameters: the graphs hold their addresses (the reference re-wraps the same storages per frame)
         for grp in self.all_planes:
             for i, p in enumerate(grp):
@@ -43,6 +45,8 @@ class GraphedSlam(Slam):
     # ------------------------------------------------------------------------------------------------------------
     def _capture(self, fn, reset):
         """Warm up `fn` on a side stream (creates optimiser state outside the graph), reset, capture."""
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -56,6 +60,8 @@ class GraphedSlam(Slam):
             fn()
         torch.cuda.synchronize()
         reset()
+        self.stats["graphs"] = self.stats.get("graphs", 0) + 1
+        self.stats["capture_seconds"] = self.stats.get("capture_seconds", 0.0) + time.perf_counter() - t0
         return g
 
     @staticmethod
@@ -77,7 +83,7 @@ class GraphedSlam(Slam):
         st.init = cam_pose.detach().clone()
         st.T = torch.nn.Parameter(st.init[:, 4:].clone())
         st.R = torch.nn.Parameter(st.init[:, :4].clone())
-        st.best = torch.full((), float("inf"), device=dev)
+        st.best = torch.full((1,), float("inf"), device=dev)
         st.best_pose = st.init.clone()
         st.opt = optim.Adam([{"params": [st.T], "lr": cfg.lr_T, "betas": (0.5, 0.999)},
                              {"params": [st.R], "lr": cfg.lr_R, "betas": (0.5, 0.999)}], capturable=True)
@@ -89,18 +95,13 @@ class GraphedSlam(Slam):
             ro, rd, gd, gc = be.get_samples(cfg.ignore_edge_H, sc.H - cfg.ignore_edge_H, cfg.ignore_edge_W,
                                             sc.W - cfg.ignore_edge_W, cfg.tracking_pixels, sc.H, sc.W, sc.fx, sc.fy,
                                             sc.cx, sc.cy, c2w, st.depth, st.color, dev)
-            with torch.no_grad():
-                keep = (be.aabb_exit(ro, rd) >= gd) & (gd > 0)                        # Tracker.py:175-182, as a mask
+            keep = ops.prefilter(ro, rd, gd, self._bound6, True)                      # Tracker.py:175-182, as a mask
             depth, color, sdf, z = be.render_batch_ray(planes, self.decoders, rd, ro, self.truncation, gd)
             loss = losses.tracking_loss(depth, color, sdf, z, gd, gc, self.truncation, cfg.tracking_w, ray_mask=keep)
             st.opt.zero_grad()
             loss.backward()
             st.opt.step()
-            with torch.no_grad():                                                     # Tracker.py:304-307 on the device
-                lv = loss.detach().reshape(())
-                better = lv < st.best
-                st.best_pose.copy_(torch.where(better, pose.detach(), st.best_pose))
-                st.best.copy_(torch.where(better, lv, st.best))
+            ops.keep_best(loss, pose, st.best, st.best_pose)                          # Tracker.py:304-307 on the device
 
         def reset():
             with torch.no_grad():
@@ -165,8 +166,7 @@ class GraphedSlam(Slam):
             c2ws_ = torch.cat([st.c2ws[0:1], be.cam_pose_to_matrix(st.cam_poses)], 0) if joint else st.c2ws
             ro, rd, gd, gc = be.get_samples(0, sc.H, 0, sc.W, pixs, sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, c2ws_, depths,
                                             colors, dev)
-            with torch.no_grad():
-                keep = be.aabb_exit(ro, rd) >= gd                                     # Mapper.py:322-328, as a mask
+            keep = ops.prefilter(ro, rd, gd, self._bound6, False)                     # Mapper.py:322-328, as a mask
             depth, color, sdf, z = be.render_batch_ray(self.all_planes, self.decoders, rd, ro, self.truncation, gd)
             loss = losses.mapping_loss(depth, color, sdf, z, gd, gc, self.truncation, cfg.mapping_w, ray_mask=keep)
             st.opt.zero_grad()

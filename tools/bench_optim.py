@@ -2,7 +2,7 @@
 (csrc/eslam_adam.hip) against torch.optim.Adam's GPU implementations on the room0 parameter set (12 planes, 6.8 M
 elements + decoders), with the gradients one real backward leaves (sparse: one camera) and with dense gradients."""
 import ctypes, sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from myslam_amd import harness, _hip, optim
 dev = torch.device('cuda:0')
 lib = _hip.lib()

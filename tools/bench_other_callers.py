@@ -1,7 +1,7 @@
 """Timings of the other callers of the path on the GPU box (not the headline metric): tracking iteration (pose gradients
 only), whole-image render (render_img, Frame_Visualizer's caller), dense field query (Mesher.eval_points' caller)."""
 import ctypes, sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from myslam_amd import harness, losses, _hip
 dev = torch.device('cuda:0')
 lib = _hip.lib()

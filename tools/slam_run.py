@@ -4,7 +4,7 @@ Replica iteration counts and pixel budgets), reporting ATE, render quality and w
     python tools/slam_run.py [n_frames] [iters_first] [eager|graph]
 """
 import sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from myslam_amd import eval_ate, scene as scn, slam, synthscene
 
 n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 41
@@ -42,6 +42,11 @@ q = s.render_quality(gc, gd, pose)
 st = s.stats
 first = marks[0] - t1
 print(f"ATE rmse {ate['rmse']*100:.2f} cm (mean {ate['mean']*100:.2f}, max {ate['max']*100:.2f}); held-out view PSNR {q['psnr']:.2f} dB, depth L1 {q['depth_l1']*100:.2f} cm")
+cap = st.get("capture_seconds", 0.0)
+if cap:
+    print(f"[{mode}] {st['graphs']} graph builds (warm-up + capture, one-time kernel loading included) {cap:.2f} s; "
+          f"loop without them {total-cap:.2f} s = {n_frames/(total-cap):.1f} frames/s, "
+          f"{(total-cap)/(st['tracking_iters']+st['mapping_iters'])*1e3:.3f} ms/iteration")
 print(f"[{mode}] loop {total:.1f} s: first-frame mapping ({iters_first} iterations) {first:.1f} s = {first/iters_first*1e3:.2f} ms/iteration; "
       f"remaining {n_frames-1} frames {total-first:.1f} s = {(n_frames-1)/(total-first):.1f} frames/s "
       f"({st['tracking_iters']} tracking + {st['mapping_iters']-iters_first} mapping iterations, "
