@@ -146,18 +146,24 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
                                                           const float* __restrict__ rays_d,
                                                           const float* __restrict__ z_vals,     // RENDER ? [R,S] : pts [N,3]
                                                           const int* __restrict__ perm, int R, int S,
-                                                          const float* __restrict__ g_feat, int bundle) {
+                                                          const float* __restrict__ g_feat, int bundle,
+                                                          int allow_counting) {
     constexpr int dbg_mode = DBG;
     constexpr int BM = 4 * NT;
     constexpr int SLOT_BITS = (BM == 1024) ? 10 : 11;
     constexpr unsigned SLOT_MASK = BM - 1;
     static_assert(BM == 1024 || BM == 2048, "bundle size");
-    __shared__ unsigned skey[BM];          // (cell << SLOT_BITS) | local sample slot, sorted
-    __shared__ unsigned sxy[BM];           // per slot: byte offset of texel (x0,y0) | minor-axis step flag | major flag << 1
-                                           // (offsets are multiples of 4: the two low bits are free)
-    __shared__ float stm[BM], stM[BM];     // per slot: bilinear fraction along the minor / major axis
-    __shared__ int sgrow[BM];              // per slot: row of g_feat (global point index)
+    __shared__ __attribute__((aligned(16))) unsigned lds_raw[5 * BM];
+    unsigned* const skey = lds_raw;                    // (cell << SLOT_BITS) | local sample slot, sorted
+    unsigned* const sxy = lds_raw + BM;                // per slot: byte offset of texel (x0,y0) | minor-axis step flag |
+                                                       // major flag << 1 (offsets are multiples of 4: two low bits free)
+    float* const stm = (float*)(lds_raw + 2 * BM);     // per slot: bilinear fraction along the minor axis
+    float* const stM = (float*)(lds_raw + 3 * BM);     // ... along the major axis
+    int* const sgrow = (int*)(lds_raw + 4 * BM);       // per slot: row of g_feat (global point index)
+    unsigned* const cnt = lds_raw + 2 * BM;            // counting sort: 4*BM packed 16-bit counters, aliasing stm/stM
+                                                       // (dead before the records are written)
     __shared__ int sbox[4];                // bounding box of the bundle's cells: xmin, xmax, ymin, ymax
+    __shared__ unsigned swsum[NT / WAVE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hx = lane >> 5, c = lane & 31;   // hx: corner along the MINOR axis
 
@@ -222,7 +228,81 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
     __syncthreads();
     // The sort key runs along the axis the bundle travels along ("minor" = fastest-varying), so that consecutive cells
     // of the sorted list are neighbours along it and share a texel column that is carried instead of flushed twice.
+    if (sbox[1] < 0) return;                                          // no valid sample in this bundle
     const bool swap = (sbox[3] - sbox[2]) > (sbox[1] - sbox[0]);      // travels along y: column-major keys
+    // Bundles whose cells fit a small box (the normal case: 32 neighbouring rays) are ordered by a counting sort over
+    // the box - one LDS integer atomic per sample, one scan, one placement pass - instead of the 66-stage bitonic
+    // network (50 us of this kernel's 165).  Rows of the box get one padding column so that "next cell along the minor
+    // axis" never wraps into the next row.  Order inside a cell is arbitrary; the cell's sum does not depend on it
+    // beyond float rounding.
+    const int mmin = swap ? sbox[2] : sbox[0], mext = (swap ? sbox[3] : sbox[1]) - mmin + 2;
+    const int Mmin = swap ? sbox[0] : sbox[2], Mext = (swap ? sbox[1] : sbox[3]) - Mmin + 1;
+    const bool counting = allow_counting && (int64_t)mext * Mext <= 4 * BM;
+    if (counting) {
+        constexpr int WPT = 2 * BM / NT;                       // counter words per thread in the scan
+        for (int i = threadIdx.x; i < 2 * BM; i += NT) cnt[i] = 0u;
+        __syncthreads();
+        unsigned loc[4], tick[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            loc[k] = 0; tick[k] = 0;
+            if (cpt[k] >= 0) {
+                const int im = swap ? cay[k].i0 : cax[k].i0, iM = swap ? cax[k].i0 : cay[k].i0;
+                loc[k] = (unsigned)((iM - Mmin) * mext + (im - mmin));
+                const unsigned sh = (loc[k] & 1u) * 16u;
+                tick[k] = (atomicAdd(&cnt[loc[k] >> 1], 1u << sh) >> sh) & 0xFFFFu;
+            }
+        }
+        __syncthreads();
+        // exclusive scan of the counters: thread t owns words [WPT t, WPT t + WPT)
+        unsigned w[WPT], local = 0;
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            w[j] = cnt[threadIdx.x * WPT + j];
+            local += (w[j] & 0xFFFFu) + (w[j] >> 16);
+        }
+        unsigned incl = local;
+#pragma unroll
+        for (int dlt = 1; dlt < WAVE; dlt <<= 1) {
+            const unsigned up = __shfl_up(incl, dlt, WAVE);
+            if (lane >= dlt) incl += up;
+        }
+        if (lane == WAVE - 1) swsum[wave] = incl;
+        __syncthreads();
+        unsigned run = incl - local, nvalid = 0;
+        for (int wv = 0; wv < NT / WAVE; ++wv) {
+            if (wv < wave) run += swsum[wv];
+            nvalid += swsum[wv];
+        }
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            const unsigned lo16 = w[j] & 0xFFFFu, hi16 = w[j] >> 16;
+            cnt[threadIdx.x * WPT + j] = run | ((run + lo16) << 16);
+            run += lo16 + hi16;
+        }
+        __syncthreads();
+        unsigned pos[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pos[k] = ((cnt[loc[k] >> 1] >> ((loc[k] & 1u) * 16u)) & 0xFFFFu) + tick[k];
+        __syncthreads();                                       // counters are dead: their memory becomes stm / stM
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (cpt[k] >= 0) {
+                const AxisCoord& am = swap ? cay[k] : cax[k];
+                const AxisCoord& aM = swap ? cax[k] : cay[k];
+                const int cell = aM.i0 * (swap ? ph : pw) + am.i0;
+                const unsigned q = pos[k];
+                skey[q] = ((unsigned)cell << SLOT_BITS) | q;    // records are stored in sorted order: slot = position
+                sxy[q] = ((unsigned)(cay[k].i0 * psy + cax[k].i0 * psx) << 2) | (unsigned)(am.i1 > am.i0) |
+                         ((unsigned)(aM.i1 > aM.i0) << 1);
+                stm[q] = am.t;
+                stM[q] = aM.t;
+                sgrow[q] = cpt[k];
+            }
+        }
+        for (int i = (int)nvalid + threadIdx.x; i < BM; i += NT) skey[i] = 0xFFFFFFFFu;
+        __syncthreads();
+    } else {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int slot = threadIdx.x + k * NT;
@@ -273,6 +353,7 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
                 }
             }
         }
+    }
     }
     if (dbg_mode == 2) return;
 
@@ -443,11 +524,12 @@ int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float*
             eslam_set_error("scatter: plane %d has %d x %d cells, limit 2^21", i, planes[i].h, planes[i].w);
             return 1;
         }
+    static const int counting = env_int("ESLAM_SC_COUNTING", 1);   // A/B switch: 0 = always the bitonic network
     const int bundle = (bm == 1024 ? 1024 : 2048) / per;
     dim3 grid((nunits + bundle - 1) / bundle, NPL);
 #define LAUNCH_SC(RD, DB, NTv, PERM, SS)                                                                               \
     hipLaunchKernelGGL((scatter_sort_kernel<RD, DB, NTv>), grid, dim3(NTv), 0, st, ps, bnd, rays_o, rays_d, z_or_pts, \
-                       PERM, (int)R, SS, g_feat, bundle)
+                       PERM, (int)R, SS, g_feat, bundle, counting)
     if (render) {
         if (dbg_mode == 1) LAUNCH_SC(true, 1, 512, perm, S);
         else if (dbg_mode == 2) LAUNCH_SC(true, 2, 512, perm, S);

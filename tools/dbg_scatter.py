@@ -1,6 +1,6 @@
 """Scatter experiments on the GPU box: time + table statistics for the settings given through ESLAM_SC_* env vars."""
 import ctypes, os, sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from myslam_amd import harness, _hip
 dev = torch.device('cuda:0')
 wl = harness.make_workload('room0', 4096, 56, 8, device=dev)

@@ -1,0 +1,90 @@
+"""CPU simulation of the ray ORDER used for bundling in the scatter: for each candidate order of the bench rays
+(room0, 4096x64), bundles of 32 consecutive rays x 12 planes -> number of distinct cells (= flush count before the
+column carry) and the share of (bundle, plane) boxes too large for the in-LDS counting sort (> 8192 padded bins)."""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from myslam_amd import scene as scn, synth
+from oracle import eslam_oracle as orc
+
+sc = scn.make_scene('room0')
+R, ns, ni = 4096, 56, 8
+S = ns + ni
+depth_img = torch.from_numpy(synth.depth_image(sc.H, sc.W, 10))[None]
+color_img = torch.from_numpy(synth.color_image(sc.H, sc.W, 12))[None]
+idx = torch.from_numpy(synth.hash_randint(sc.H * sc.W, (R,), 50_000))
+c2w = scn.center_pose(sc)[None]
+ro, rd, gd, gc = orc.rays_from_pixels(idx, 0, sc.H, 0, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, c2w, depth_img, color_img)
+z = orc.depth_guided_z(gd, ns, ni, 0.06, torch.from_numpy(synth.hash_uniform((R, S), 90_000)))
+pn = orc.normalize_points(ro[:, None, :] + rd[:, None, :] * z[..., None], sc.bound).reshape(R, S, 3).numpy()
+
+def spread(v, bits):
+    out = np.zeros_like(v, dtype=np.uint64)
+    for b in range(bits):
+        out |= ((v >> b) & 1).astype(np.uint64) << (3 * b)
+    return out
+
+def spread2(v, bits):
+    out = np.zeros_like(v, dtype=np.uint64)
+    for b in range(bits):
+        out |= ((v >> b) & 1).astype(np.uint64) << (2 * b)
+    return out
+
+p1 = (ro + rd / rd.norm(dim=1, keepdim=True)).numpy()
+
+def morton3(bits):
+    lo, hi = p1.min(0), p1.max(0)
+    q = np.clip(((p1 - lo) / np.maximum(hi - lo, 1e-6) * (1 << bits)).astype(np.int64), 0, (1 << bits) - 1)
+    return spread(q[:, 0], bits) | (spread(q[:, 1], bits) << 1) | (spread(q[:, 2], bits) << 2)
+
+def pca2(bits, hilbert=False):
+    """2-D order in the two dominant principal axes of the 1-m points (a camera's rays are a 2-D patch of a sphere)."""
+    c = p1 - p1.mean(0)
+    _, _, vt = np.linalg.svd(c, full_matrices=False)
+    uv = c @ vt[:2].T
+    lo, hi = uv.min(0), uv.max(0)
+    q = np.clip(((uv - lo) / np.maximum(hi - lo, 1e-6) * (1 << bits)).astype(np.int64), 0, (1 << bits) - 1)
+    if not hilbert:
+        return spread2(q[:, 0], bits) | (spread2(q[:, 1], bits) << 1)
+    x, y = q[:, 0].copy(), q[:, 1].copy()
+    d = np.zeros(len(x), dtype=np.int64)
+    s = 1 << (bits - 1)
+    while s > 0:
+        rx = ((x & s) > 0).astype(np.int64); ry = ((y & s) > 0).astype(np.int64)
+        d += s * s * ((3 * rx) ^ ry)
+        flip = (ry == 0) & (rx == 1)
+        x = np.where(flip, s - 1 - x, x); y = np.where(flip, s - 1 - y, y)
+        sw = ry == 0
+        x, y = np.where(sw, y, x), np.where(sw, x, y)
+        s >>= 1
+    return d
+
+orders = {"given (random pixels)": np.arange(R), "3-D Morton 5 bits/axis (kernel)": np.argsort(morton3(5), kind='stable'),
+          "3-D Morton 10 bits/axis": np.argsort(morton3(10), kind='stable'),
+          "2-D Morton (PCA plane) 8 bits": np.argsort(pca2(8), kind='stable'),
+          "2-D Hilbert (PCA plane) 8 bits": np.argsort(pca2(8, True), kind='stable')}
+B = 32
+print(f"{'order':34s} {'distinct cells':>14s} {'carried flushes':>16s} {'boxes > 8192 bins':>18s}")
+for name, order in orders.items():
+    cells_tot = flush_tot = 0
+    big = nbox = 0
+    for d in range(2):
+        for lvl in range(2):
+            for o, (a, b) in enumerate([(0, 1), (0, 2), (1, 2)]):
+                shp = sc.plane_shapes[3 * d + o][lvl]
+                h, w = shp[2], shp[3]
+                x0 = np.floor(np.clip((pn[..., a] + 1) / 2 * (w - 1), 0, w - 1)).astype(np.int64)[order]
+                y0 = np.floor(np.clip((pn[..., b] + 1) / 2 * (h - 1), 0, h - 1)).astype(np.int64)[order]
+                for i in range(0, R, B):
+                    xs, ys = x0[i:i + B].ravel(), y0[i:i + B].ravel()
+                    ex, ey = xs.max() - xs.min(), ys.max() - ys.min()
+                    swap = ey > ex
+                    m, M = (ys, xs) if swap else (xs, ys)
+                    mext, Mext = m.max() - m.min() + 2, M.max() - M.min() + 1
+                    nbox += 1
+                    big += mext * Mext > 8192
+                    cell = np.unique(M * 100000 + m)
+                    cells_tot += len(cell)
+                    # with the column carry a cell adjacent (along the minor axis) to its predecessor costs half a flush
+                    adj = np.concatenate([[False], np.diff(cell) == 1])
+                    flush_tot += len(cell) - 0.5 * adj.sum()
+    print(f"{name:34s} {cells_tot:14d} {flush_tot:16.0f} {100*big/nbox:17.1f}%")
