@@ -100,6 +100,13 @@ int eslam_importance_z(const eslam_plane_t* planes, const eslam_decoders_t* dec,
                        int n_imp, const float* t_free, const float* t_rand_uni, const float* u, float* z_vals,
                        eslam_stream_t stream);
 
+/* eslam_sample_z + eslam_importance_z in ONE launch: every row of z_vals [R, n_strat+n_imp] - rays with gt_depth > 0 by
+ * the depth-guided rule (bit-exact, as eslam_sample_z), the others by the importance sampler.  Needs n_strat >= 3.    */
+int eslam_sample_z_all(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
+                       const float* rays_o, const float* rays_d, const float* gt_depth, int R, int n_strat, int n_imp,
+                       double truncation, const float* t_free, const float* t_surf, const float* t_rand,
+                       const float* t_rand_uni, const float* u, float* z_vals, eslam_stream_t stream);
+
 /* K5-K7 forward.  Replaces src/utils/Renderer.py:136-147 + src/networks/decoders.py:64-146 +
  * src/common.py:204-218:  pts = o + d z -> normalise -> tri-plane bilinear gather (border, align_corners) ->
  * SDF / colour MLPs -> sdf2alpha -> transmittance scan -> composite.
@@ -250,6 +257,16 @@ int eslam_tracking_mask(const float* depth, const float* gt_depth, const uint8_t
                         uint8_t* mask, eslam_stream_t stream);
 int eslam_keep_best(const float* loss, const float* pose, int n, float* best, float* best_pose,
                     eslam_stream_t stream);
+
+/* Single-GPU forward of the fused loss in ONE launch: the sums of eslam_loss_reduce, acc [ESLAM_LOSS_ACC] (overwritten -
+ * no pre-zeroing) and the loss value [1] (may be NULL).  scratch: ESLAM_LOSS_SCRATCH floats that the caller zeroes ONCE
+ * when allocating them and then only hands to this function (it holds a self-resetting ticket counter and the
+ * running sums, one cache line each; one scratch per concurrently running stream).  eslam_loss_grad(acc) gives the gradients. */
+#define ESLAM_LOSS_SCRATCH (32 * 17)
+int eslam_loss_value(const float* depth, const float* rgb, const float* sdf, const float* z_vals,
+                     const float* gt_depth, const float* gt_color, int R, int S, double truncation,
+                     const float* weights5_host, const uint8_t* ray_mask, float* scratch, float* acc, float* loss,
+                     eslam_stream_t stream);
 
 /* Per-kernel device timing for bench.py's roofline line (HIP events recorded on the launch stream around each
  * kernel while enabled; adds nothing to the launch path when disabled).  Usage: enable(1); run one iteration;

@@ -45,6 +45,7 @@ SIGNATURES = {
     "eslam_aabb_exit": (_i, [_vp, _vp, _i, _BP, _vp, _vp]),
     "eslam_sample_z": (_i, [_vp, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp]),
     "eslam_importance_z": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "eslam_sample_z_all": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "eslam_render_fwd": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "eslam_render_fwd_lowp": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "eslam_ray_order": (_i, [_vp, _vp, _i, _vp, _vp]),
@@ -59,6 +60,7 @@ SIGNATURES = {
     "eslam_profile_read": (_i, [_BP]),
     "eslam_profile_name": (ctypes.c_char_p, [_i]),
     "eslam_loss_grad": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _BP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "eslam_loss_value": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _BP, _vp, _vp, _vp, _vp, _vp]),
     "eslam_adam_step": (_i, [_vp, _i, _i, _vp, _d, _d, _d, _i, _vp]),
     "eslam_prefilter": (_i, [_vp, _vp, _vp, _i, _BP, _i, _vp, _vp]),
     "eslam_pose_to_c2w": (_i, [_vp, _i, _vp, _vp]),

@@ -24,12 +24,19 @@ __device__ __forceinline__ int sdf_region(float z, float d, Trunc tr) {
     return 2;
 }
 
+// FINAL = false: the sums are added to acc with one atomic per workgroup and accumulator (acc pre-zeroed by the caller; the
+//   data-parallel path all-reduces acc before anything is derived from it).
+// FINAL = true: single-GPU path, one launch and no buffer to pre-zero per call: every workgroup adds its sums to a
+//   persistent scratch and takes a ticket; the workgroup that draws the last ticket moves the totals to acc [16], writes
+//   the loss value and leaves the scratch zeroed for the next call.
+template <bool FINAL>
 __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ depth, const float* __restrict__ rgb,
                                                           const float* __restrict__ sdf, const float* __restrict__ z_vals,
                                                           const float* __restrict__ gt_depth,
                                                           const float* __restrict__ gt_color,
                                                           const uint8_t* __restrict__ ray_mask, int R, int S, const Trunc tr,
-                                                          float* __restrict__ acc) {
+                                                          float* __restrict__ acc, float* __restrict__ scratch,
+                                                          const LossW w, float* __restrict__ loss) {
     // grid-stride over rays: the 10 accumulators share one cache line, and same-line float atomics serialise at the
     // memory side (~12 ns each), so the number of workgroups - not of rays - sets the cost of the final adds
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -60,9 +67,41 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restric
         if (lane == 0) red[wave][k] = s;
     }
     __syncthreads();
-    if (threadIdx.x < A_COUNT) {
-        const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        if (s != 0.0f) atomicAdd(acc + threadIdx.x, s);
+    float tot = 0.0f;
+    if (threadIdx.x < A_COUNT)
+        tot = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (!FINAL) {
+        if (threadIdx.x < A_COUNT && tot != 0.0f) atomicAdd(acc + threadIdx.x, tot);
+        return;
+    }
+    // scratch: [0] ticket counter (unsigned); accumulator k at scratch[32 * (k + 1)] - one 128-B line each, so the float
+    // atomics of different accumulators go to different memory channels.  Everything is exchanged through device-scope
+    // atomics (performed at the memory side, the one point all XCDs agree on): a release fence instead would write back
+    // each XCD's L2 - full of the forward's freshly written features at this point - and cost 20 us.
+    // Every adder waits for its atomic's return value before the workgroup takes its ticket, so the workgroup that draws
+    // the last ticket sees all sums; it swaps them out for zeros, which leaves the scratch ready for the next call.
+    __shared__ unsigned ticket;
+    if (threadIdx.x < A_COUNT && tot != 0.0f) {
+        const float old = atomicAdd(scratch + 32 * (threadIdx.x + 1), tot);
+        asm volatile("" ::"v"(old));                    // the add has been performed once its result is back
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) ticket = atomicAdd((unsigned*)scratch, 1u);
+    __syncthreads();
+    if (ticket != gridDim.x - 1) return;
+    __shared__ float fin[16];
+    if (threadIdx.x < 16) {
+        const float v = threadIdx.x < A_COUNT ? atomicExch(scratch + 32 * (threadIdx.x + 1), 0.0f) : 0.0f;
+        fin[threadIdx.x] = v;
+        acc[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (loss)      // torch.mean over an empty set is NaN (0/0); keep that behaviour
+            loss[0] = w.fs * (fin[A_S_FRONT] / fin[A_N_FRONT]) + w.center * (fin[A_S_CENTER] / fin[A_N_CENTER]) +
+                      w.tail * (fin[A_S_TAIL] / fin[A_N_TAIL]) + w.color * (fin[A_S_COLOR] / fin[A_N_COLOR]) +
+                      w.depth * (fin[A_S_DEPTH] / fin[A_N_DEPTH]);
+        atomicExch((unsigned*)scratch, 0u);
     }
 }
 
@@ -131,9 +170,27 @@ extern "C" int eslam_loss_reduce(const float* depth, const float* rgb, const flo
         return 1;
     }
     const int nwg = (R + 3) / 4 < 256 ? (R + 3) / 4 : 256;
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, depth, rgb, sdf, z_vals,
-                       gt_depth, gt_color, ray_mask, R, S, make_trunc(truncation), acc);
+    hipLaunchKernelGGL(loss_reduce_kernel<false>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, depth, rgb, sdf, z_vals,
+                       gt_depth, gt_color, ray_mask, R, S, make_trunc(truncation), acc, (float*)nullptr, LossW{}, (float*)nullptr);
     return eslam_check_launch("loss_reduce_kernel");
+}
+
+extern "C" int eslam_loss_value(const float* depth, const float* rgb, const float* sdf, const float* z_vals,
+                                const float* gt_depth, const float* gt_color, int R, int S, double truncation,
+                                const float* weights5_host, const uint8_t* ray_mask, float* scratch, float* acc,
+                                float* loss, eslam_stream_t stream) {
+    if (!loss_args_ok("eslam_loss_value", depth, rgb, sdf, z_vals, gt_depth, gt_color, R, S)) return 1;
+    if (!weights5_host || !scratch || !acc) {
+        eslam_set_error("eslam_loss_value: null argument");
+        return 1;
+    }
+    const LossW w = {weights5_host[0], weights5_host[1], weights5_host[2], weights5_host[3], weights5_host[4]};
+    const int nwg = (R + 3) / 4 < 256 ? (R + 3) / 4 : 256;
+    eslam_prof_begin(PROF_LOSS, (hipStream_t)stream);
+    hipLaunchKernelGGL(loss_reduce_kernel<true>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, depth, rgb, sdf, z_vals,
+                       gt_depth, gt_color, ray_mask, R, S, make_trunc(truncation), acc, scratch, w, loss);
+    eslam_prof_end(PROF_LOSS, (hipStream_t)stream);
+    return eslam_check_launch("loss_reduce_kernel<final>");
 }
 
 extern "C" int eslam_loss_grad(const float* depth, const float* rgb, const float* sdf, const float* z_vals,

@@ -167,19 +167,12 @@ __device__ __forceinline__ float jitter_one(const float* zs, int i, int S, float
     return __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), t));
 }
 
-__global__ __launch_bounds__(256) void sample_z_kernel(const float* __restrict__ gt_depth, int R, int n_strat,
-                                                       int n_imp, float c15, float c3,
-                                                       const float* __restrict__ t_free,
-                                                       const float* __restrict__ t_surf,
-                                                       const float* __restrict__ t_rand, float* __restrict__ z_vals) {
-    __shared__ float zs_all[4][ESLAM_MAX_SAMPLES];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ray = blockIdx.x * 4 + wave;
-    if (ray >= R) return;
-    const float d = gt_depth[ray];
-    if (!(d > 0.0f)) return;                       // Renderer.py:92: handled by the importance sampler
+// one wave: the S depth-guided samples of one ray with depth d > 0 (zs: S floats of LDS owned by the wave)
+__device__ __forceinline__ void depth_guided_row(float d, int ray, int n_strat, int n_imp, float c15, float c3,
+                                                 const float* __restrict__ t_free, const float* __restrict__ t_surf,
+                                                 const float* __restrict__ t_rand, float* __restrict__ z_vals, float* zs,
+                                                 int lane) {
     const int S = n_strat + n_imp;
-    float* zs = zs_all[wave];
     const float d12 = __fmul_rn(1.2f, d);          // Renderer.py:100
     const float dlo = __fsub_rn(d, c15);           // Renderer.py:97
     for (int i = lane; i < S; i += WAVE) {
@@ -205,10 +198,26 @@ __global__ __launch_bounds__(256) void sample_z_kernel(const float* __restrict__
         out[i] = t_rand ? jitter_one(zs, i, S, t_rand[(int64_t)ray * S + i]) : zs[i];
 }
 
+__global__ __launch_bounds__(256) void sample_z_kernel(const float* __restrict__ gt_depth, int R, int n_strat,
+                                                       int n_imp, float c15, float c3,
+                                                       const float* __restrict__ t_free,
+                                                       const float* __restrict__ t_surf,
+                                                       const float* __restrict__ t_rand, float* __restrict__ z_vals) {
+    __shared__ float zs_all[4][ESLAM_MAX_SAMPLES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ray = blockIdx.x * 4 + wave;
+    if (ray >= R) return;
+    const float d = gt_depth[ray];
+    if (!(d > 0.0f)) return;                       // Renderer.py:92: handled by the importance sampler
+    depth_guided_row(d, ray, n_strat, n_imp, c15, c3, t_free, t_surf, t_rand, z_vals, zs_all[wave], lane);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // K4: reference src/utils/Renderer.py:108-134 + src/common.py:41-77.  One wave per zero-depth ray.
 // ---------------------------------------------------------------------------------------------------------
-template <bool CL>
+// WITH_DEPTH: the same launch also produces the rows of the rays WITH depth (K3) before it looks for depth-less ones -
+// one launch instead of two for the whole z_vals tensor (most batches have no depth-less ray and leave right after).
+template <bool CL, bool WITH_DEPTH>
 __global__ __launch_bounds__(256, 2) void importance_z_kernel(const PlaneSet planes, const eslam_decoders_t dec,
                                                            const Bound bnd, const float* __restrict__ rays_o,
                                                            const float* __restrict__ rays_d,
@@ -216,11 +225,22 @@ __global__ __launch_bounds__(256, 2) void importance_z_kernel(const PlaneSet pla
                                                            int n_imp, const float* __restrict__ t_free,
                                                            const float* __restrict__ t_rand_uni,
                                                            const float* __restrict__ u_rand,
-                                                           float* __restrict__ z_vals) {
+                                                           float* __restrict__ z_vals, float c15, float c3,
+                                                           const float* __restrict__ t_surf,
+                                                           const float* __restrict__ t_rand) {
     __shared__ __attribute__((aligned(16))) float wlds[2 * DEC_LDS];
     __shared__ float zu_all[4][ESLAM_MAX_SAMPLES];      // jittered uniform samples, then the merged list
     __shared__ float wt_all[4][ESLAM_MAX_SAMPLES];      // weights -> cdf
     __shared__ float zn_all[4][ESLAM_MAX_SAMPLES];      // importance samples
+    if (WITH_DEPTH) {
+        const int ray0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (ray0 < R) {
+            const float d0 = gt_depth[ray0];
+            if (d0 > 0.0f)
+                depth_guided_row(d0, ray0, n_strat, n_imp, c15, c3, t_free, t_surf, t_rand, z_vals,
+                                 zu_all[threadIdx.x >> 6], threadIdx.x & 63);
+        }
+    }
     {   // most batches have no depth-less ray at all: leave before the 11 KB of weights are staged
         bool any = false;
         for (int w = 0; w < 4; ++w) {
@@ -461,11 +481,46 @@ extern "C" int eslam_importance_z(const eslam_plane_t* planes, const eslam_decod
     dim3 grid((R + 3) / 4), block(256);
     eslam_prof_begin(PROF_IMPORTANCE_Z, (hipStream_t)stream);
     if (eslam_planes_channels_last(planes, 0, 6))
-        hipLaunchKernelGGL((importance_z_kernel<true>), grid, block, 0, (hipStream_t)stream, ps, *dec, bnd, rays_o,
-                           rays_d, gt_depth, R, n_strat, n_imp, t_free, t_rand_uni, u, z_vals);
+        hipLaunchKernelGGL((importance_z_kernel<true, false>), grid, block, 0, (hipStream_t)stream, ps, *dec, bnd, rays_o,
+                           rays_d, gt_depth, R, n_strat, n_imp, t_free, t_rand_uni, u, z_vals, 0.0f, 0.0f,
+                           (const float*)nullptr, (const float*)nullptr);
     else
-        hipLaunchKernelGGL((importance_z_kernel<false>), grid, block, 0, (hipStream_t)stream, ps, *dec, bnd, rays_o,
-                           rays_d, gt_depth, R, n_strat, n_imp, t_free, t_rand_uni, u, z_vals);
+        hipLaunchKernelGGL((importance_z_kernel<false, false>), grid, block, 0, (hipStream_t)stream, ps, *dec, bnd, rays_o,
+                           rays_d, gt_depth, R, n_strat, n_imp, t_free, t_rand_uni, u, z_vals, 0.0f, 0.0f,
+                           (const float*)nullptr, (const float*)nullptr);
     eslam_prof_end(PROF_IMPORTANCE_Z, (hipStream_t)stream);
     return eslam_check_launch("importance_z_kernel");
+}
+
+extern "C" int eslam_sample_z_all(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
+                                  const float* rays_o, const float* rays_d, const float* gt_depth, int R, int n_strat,
+                                  int n_imp, double truncation, const float* t_free, const float* t_surf,
+                                  const float* t_rand, const float* t_rand_uni, const float* u, float* z_vals,
+                                  eslam_stream_t stream) {
+    if (R <= 0) return 0;
+    if (n_strat < 3 || n_imp < 0 || n_strat + n_imp > ESLAM_MAX_SAMPLES) {
+        eslam_set_error("eslam_sample_z_all: n_strat=%d n_imp=%d unsupported", n_strat, n_imp);
+        return 1;
+    }
+    if (!planes || !dec || !bound6_host || !rays_o || !rays_d || !gt_depth || !t_free || (n_imp > 0 && (!u || !t_surf)) ||
+        !z_vals) {
+        eslam_set_error("eslam_sample_z_all: null argument");
+        return 1;
+    }
+    if (eslam_validate_planes(planes, 0, 6)) return 1;
+    PlaneSet ps;
+    for (int i = 0; i < NPL; ++i) ps.p[i] = planes[i < 6 ? i : i - 6];
+    const Bound bnd = make_bound(bound6_host);
+    const float c15 = (float)(1.5 * truncation);       // as eslam_sample_z
+    const float c3 = (float)(3.0 * truncation);
+    dim3 grid((R + 3) / 4), block(256);
+    eslam_prof_begin(PROF_SAMPLE_Z, (hipStream_t)stream);
+    if (eslam_planes_channels_last(planes, 0, 6))
+        hipLaunchKernelGGL((importance_z_kernel<true, true>), grid, block, 0, (hipStream_t)stream, ps, *dec, bnd, rays_o,
+                           rays_d, gt_depth, R, n_strat, n_imp, t_free, t_rand_uni, u, z_vals, c15, c3, t_surf, t_rand);
+    else
+        hipLaunchKernelGGL((importance_z_kernel<false, true>), grid, block, 0, (hipStream_t)stream, ps, *dec, bnd, rays_o,
+                           rays_d, gt_depth, R, n_strat, n_imp, t_free, t_rand_uni, u, z_vals, c15, c3, t_surf, t_rand);
+    eslam_prof_end(PROF_SAMPLE_Z, (hipStream_t)stream);
+    return eslam_check_launch("importance_z_kernel<with depth>");
 }

@@ -451,16 +451,27 @@ def sample_z(rays_o, rays_d, gt_depth, all_planes, decoders, bound6, truncation,
     t_free, t_surf = linspace01(n_strat, dev), linspace01(n_imp, dev)
     with _hip.on_device(dev):
         st = _hip.stream_handle(dev)
-        _hip.check(lib.eslam_sample_z(_hip.ptr(gd), R, n_strat, n_imp, float(truncation), _hip.ptr(t_free),
-                                      _hip.ptr(t_surf), _hip.ptr(t_rand), _hip.ptr(z), st), "eslam_sample_z")
-        if u is not None:
+        if u is not None and n_strat >= 3:
+            # both samplers in one launch (each wave takes the rule its ray needs)
             ro, rd = _c(rays_o.detach()), _c(rays_d.detach())
             arr, _ = _hip.make_planes(tuple([p.detach() for p in grp] for grp in all_planes))
             dec, keep = _hip.make_decoders([p.detach() for p in decoder_params(decoders)],
                                            beta_tensor(decoders.beta, dev).detach())
-            _hip.check(lib.eslam_importance_z(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(ro),
-                                              _hip.ptr(rd), _hip.ptr(gd), R, n_strat, n_imp, _hip.ptr(t_free),
-                                              _hip.ptr(t_uni), _hip.ptr(u), _hip.ptr(z), st), "eslam_importance_z")
+            _hip.check(lib.eslam_sample_z_all(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(ro), _hip.ptr(rd),
+                                              _hip.ptr(gd), R, n_strat, n_imp, float(truncation), _hip.ptr(t_free),
+                                              _hip.ptr(t_surf), _hip.ptr(t_rand), _hip.ptr(t_uni), _hip.ptr(u),
+                                              _hip.ptr(z), st), "eslam_sample_z_all")
+        else:
+            _hip.check(lib.eslam_sample_z(_hip.ptr(gd), R, n_strat, n_imp, float(truncation), _hip.ptr(t_free),
+                                          _hip.ptr(t_surf), _hip.ptr(t_rand), _hip.ptr(z), st), "eslam_sample_z")
+            if u is not None:        # fewer than 3 stratified samples: the importance sampler reports it as unsupported
+                ro, rd = _c(rays_o.detach()), _c(rays_d.detach())
+                arr, _ = _hip.make_planes(tuple([p.detach() for p in grp] for grp in all_planes))
+                dec, keep = _hip.make_decoders([p.detach() for p in decoder_params(decoders)],
+                                               beta_tensor(decoders.beta, dev).detach())
+                _hip.check(lib.eslam_importance_z(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(ro),
+                                                  _hip.ptr(rd), _hip.ptr(gd), R, n_strat, n_imp, _hip.ptr(t_free),
+                                                  _hip.ptr(t_uni), _hip.ptr(u), _hip.ptr(z), st), "eslam_importance_z")
     return z
 
 
@@ -483,6 +494,14 @@ def loss_reduce(depth, rgb, sdf, z_vals, gt_depth, gt_color, truncation, ray_mas
     return acc
 
 
+def _loss_scratch(dev):
+    """ESLAM_LOSS_SCRATCH floats per device: zeroed once here, then owned by eslam_loss_value's ticket scheme.  One per
+    device, not per stream: a graph capture runs on a stream of its own and must find the buffer of the warm-up (a
+    buffer created inside the capture would be re-zeroed by a captured fill on every replay).  Loss evaluations of one
+    process are therefore expected on one stream at a time - the reference's loops are single-stream."""
+    return _cached(("loss_scratch", dev.index), lambda: torch.zeros(32 * 17, device=dev))
+
+
 class MappingLossFn(torch.autograd.Function):
     """loss = MappingLossFn.apply(depth, rgb, sdf, z_vals, gt_depth, gt_color, truncation, weights5, ray_mask, group, acc)
 
@@ -496,20 +515,30 @@ class MappingLossFn(torch.autograd.Function):
     def forward(ctx, depth, rgb, sdf, z_vals, gt_depth, gt_color, truncation, weights5, ray_mask, group, acc):
         if ray_mask is not None:
             ray_mask = _c(ray_mask.view(torch.uint8) if ray_mask.dtype == torch.bool else ray_mask.to(torch.uint8))
-        if acc is None:
-            acc = loss_reduce(depth, rgb, sdf, z_vals, gt_depth, gt_color, truncation, ray_mask)
-            if group is not None:
-                import torch.distributed as dist
-                dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=None if group is True else group)
+        for n, t in (("depth", depth), ("rgb", rgb), ("sdf", sdf), ("z_vals", z_vals), ("gt_depth", gt_depth),
+                     ("gt_color", gt_color)):
+            _hip.require_gpu_f32(n, t)
         dev = depth.device
         R, S = sdf.shape
         args = [_c(t.detach()) for t in (depth, rgb, sdf, z_vals, gt_depth, gt_color)]
         loss = torch.empty(1, device=dev)
         w = (ctypes.c_float * 5)(*[float(v) for v in weights5])
-        with _hip.on_device(dev):
-            _hip.check(_hip.lib().eslam_loss_grad(*[_hip.ptr(t) for t in args], R, S, float(truncation), w,
-                                                  _hip.ptr(ray_mask), _hip.ptr(acc), _hip.ptr(loss), None, None, None,
-                                                  None, _hip.stream_handle(dev)), "eslam_loss_grad(value)")
+        if acc is None and group is None:
+            # single GPU: sums, set sizes and the value in one launch, no pre-zeroed accumulator
+            acc = torch.empty(16, device=dev)
+            with _hip.on_device(dev):
+                _hip.check(_hip.lib().eslam_loss_value(*[_hip.ptr(t) for t in args], R, S, float(truncation), w,
+                                                       _hip.ptr(ray_mask), _hip.ptr(_loss_scratch(dev)), _hip.ptr(acc),
+                                                       _hip.ptr(loss), _hip.stream_handle(dev)), "eslam_loss_value")
+        else:
+            if acc is None:
+                acc = loss_reduce(depth, rgb, sdf, z_vals, gt_depth, gt_color, truncation, ray_mask)
+                import torch.distributed as dist
+                dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=None if group is True else group)
+            with _hip.on_device(dev):
+                _hip.check(_hip.lib().eslam_loss_grad(*[_hip.ptr(t) for t in args], R, S, float(truncation), w,
+                                                      _hip.ptr(ray_mask), _hip.ptr(acc), _hip.ptr(loss), None, None, None,
+                                                      None, _hip.stream_handle(dev)), "eslam_loss_grad(value)")
         ctx.save_for_backward(*args, acc)
         ctx.ray_mask = ray_mask
         ctx.consts = (float(truncation), tuple(float(v) for v in weights5))
