@@ -147,7 +147,7 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
                                                           const float* __restrict__ z_vals,     // RENDER ? [R,S] : pts [N,3]
                                                           const int* __restrict__ perm, int R, int S,
                                                           const float* __restrict__ g_feat, int bundle,
-                                                          int allow_counting) {
+                                                          int allow_counting, int nbundles, int xcd_map) {
     constexpr int dbg_mode = DBG;
     constexpr int BM = 4 * NT;
     constexpr int SLOT_BITS = (BM == 1024) ? 10 : 11;
@@ -167,7 +167,22 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hx = lane >> 5, c = lane & 31;   // hx: corner along the MINOR axis
 
-    const int pi = blockIdx.y;                               // plane index in all_planes order
+    // Workgroup -> (bundle, plane).  The three planes of one (decoder, level) read the SAME 128-byte segment of every
+    // g_feat row of the bundle; g_feat (134 MB) does not stay in a 4 MB L2, so those three workgroups are made
+    // neighbours in time on ONE XCD (workgroups are dealt round-robin over the 8 XCDs, each with its own L2): with the
+    // plain (bundle, plane) grid 81 % of the walk's row reads missed L2.
+    int bidx, pi;
+    if (xcd_map) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int q = (j / 3) * 8 + xcd;                     // (bundle, segment) pair handled by this XCD slot
+        if (q >= nbundles * 4) return;
+        const int seg = q & 3;                               // decoder * 2 + level
+        bidx = q >> 2;
+        pi = (seg >> 1) * 6 + (j % 3) * 2 + (seg & 1);
+    } else {
+        bidx = blockIdx.x;
+        pi = blockIdx.y;                                     // plane index in all_planes order
+    }
     const int d = pi / 6, o = (pi % 6) >> 1, lvl = pi & 1;
     const eslam_plane_t& P = planes.p[pi];
     const int pw = P.w, ph = P.h;
@@ -176,7 +191,7 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
     const int64_t npts = RENDER ? (int64_t)R * S : (int64_t)R;       // decode mode: R = N points, unit = 64 points
     const int nunits = RENDER ? R : (int)((npts + 63) / 64);
     const int per = RENDER ? S : 64;                                  // samples per unit
-    const int u0 = blockIdx.x * bundle;
+    const int u0 = bidx * bundle;
     const int nu = min(bundle, nunits - u0);
     const int n = nu * per;                                           // <= BM by construction of `bundle`
 
@@ -526,10 +541,13 @@ int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float*
         }
     static const int counting = env_int("ESLAM_SC_COUNTING", 1);   // A/B switch: 0 = always the bitonic network
     const int bundle = (bm == 1024 ? 1024 : 2048) / per;
-    dim3 grid((nunits + bundle - 1) / bundle, NPL);
+    static const int xcd_map = env_int("ESLAM_SC_XCDMAP", 1);      // A/B switch: 0 = plain (bundle, plane) grid
+    const int nbundles = (nunits + bundle - 1) / bundle;
+    dim3 grid(nbundles, NPL);
+    if (xcd_map) grid = dim3(((nbundles * 4 + 7) / 8) * 8 * 3, 1);
 #define LAUNCH_SC(RD, DB, NTv, PERM, SS)                                                                               \
     hipLaunchKernelGGL((scatter_sort_kernel<RD, DB, NTv>), grid, dim3(NTv), 0, st, ps, bnd, rays_o, rays_d, z_or_pts, \
-                       PERM, (int)R, SS, g_feat, bundle, counting)
+                       PERM, (int)R, SS, g_feat, bundle, counting, nbundles, xcd_map)
     if (render) {
         if (dbg_mode == 1) LAUNCH_SC(true, 1, 512, perm, S);
         else if (dbg_mode == 2) LAUNCH_SC(true, 2, 512, perm, S);
