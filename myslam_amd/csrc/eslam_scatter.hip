@@ -23,6 +23,7 @@
 #include "eslam_decode_tile.h"
 
 #define SORT_MAX 8192
+typedef float float2_t __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------------------------
 // ray ordering
@@ -153,17 +154,27 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
     constexpr int SLOT_BITS = (BM == 1024) ? 10 : 11;
     constexpr unsigned SLOT_MASK = BM - 1;
     static_assert(BM == 1024 || BM == 2048, "bundle size");
-    __shared__ __attribute__((aligned(16))) unsigned lds_raw[5 * BM];
-    unsigned* const skey = lds_raw;                    // (cell << SLOT_BITS) | local sample slot, sorted
-    unsigned* const sxy = lds_raw + BM;                // per slot: byte offset of texel (x0,y0) | minor-axis step flag |
-                                                       // major flag << 1 (offsets are multiples of 4: two low bits free)
-    float* const stm = (float*)(lds_raw + 2 * BM);     // per slot: bilinear fraction along the minor axis
-    float* const stM = (float*)(lds_raw + 3 * BM);     // ... along the major axis
-    int* const sgrow = (int*)(lds_raw + 4 * BM);       // per slot: row of g_feat (global point index)
-    unsigned* const cnt = lds_raw + 2 * BM;            // counting sort: 4*BM packed 16-bit counters, aliasing stm/stM
-                                                       // (dead before the records are written)
-    __shared__ int sbox[4];                // bounding box of the bundle's cells: xmin, xmax, ymin, ymax
-    __shared__ unsigned swsum[NT / WAVE];
+    // 6*BM words (48 KB at BM = 2048; 3 workgroups per CU).  Layout the walk reads, records in SORTED order:
+    //   sw    [BM] float4  bilinear weights of the entry for lane halves hx = 0 / 1 and rows 0 / 1:
+    //                      ((1-tm)(1-tM), (1-tm)tM, tm(1-tM), tm tM) - a lane reads its (row 0, row 1) pair with one
+    //                      ds_read_b64, so the per-entry VALU work of the walk is ONE packed FMA
+    //   sxy   [BM] byte offset of texel (x0,y0) << 2 | minor-axis step flag | major flag << 1; 0xFFFFFFFF = padding
+    //   sgrow [BM] row of g_feat (global point index)
+    // The sort phases use the same memory differently (see below).
+    __shared__ __attribute__((aligned(16))) unsigned lds_raw[6 * BM];
+    float4_t* const sw = (float4_t*)lds_raw;
+    unsigned* const sxy = lds_raw + 4 * BM;
+    int* const sgrow = (int*)(lds_raw + 5 * BM);
+    unsigned* const cnt = lds_raw;                     // counting sort: 4*BM packed 16-bit counters (dead before sw is written)
+    unsigned* const swsum = lds_raw + 2 * BM;          // counting sort: per-wave totals of the scan
+    int* const sbox = (int*)(lds_raw + 2 * BM + 64);   // bounding box of the bundle's cells (registers before sw is written)
+    // bitonic fallback (boxes too large for the counters): keys + slot-indexed temporaries, permuted into the layout above
+    unsigned* const skey = lds_raw;                    // (cell << SLOT_BITS) | local sample slot
+    unsigned* const txy = lds_raw + BM;
+    float* const ttm = (float*)(lds_raw + 2 * BM + 128);   // after sbox / swsum
+    float* const ttM = (float*)(lds_raw + 3 * BM + 128);
+    int* const trow = (int*)(lds_raw + 4 * BM + 128);
+    constexpr unsigned PAD_XY = 0xFFFFFFFFu;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hx = lane >> 5, c = lane & 31;   // hx: corner along the MINOR axis
 
@@ -243,15 +254,17 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
     __syncthreads();
     // The sort key runs along the axis the bundle travels along ("minor" = fastest-varying), so that consecutive cells
     // of the sorted list are neighbours along it and share a texel column that is carried instead of flushed twice.
-    if (sbox[1] < 0) return;                                          // no valid sample in this bundle
-    const bool swap = (sbox[3] - sbox[2]) > (sbox[1] - sbox[0]);      // travels along y: column-major keys
+    const int bxmin = sbox[0], bxmax = sbox[1], bymin = sbox[2], bymax = sbox[3];
+    __syncthreads();                                                  // sbox's memory is reused from here on
+    if (bxmax < 0) return;                                            // no valid sample in this bundle
+    const bool swap = (bymax - bymin) > (bxmax - bxmin);              // travels along y: column-major keys
     // Bundles whose cells fit a small box (the normal case: 32 neighbouring rays) are ordered by a counting sort over
     // the box - one LDS integer atomic per sample, one scan, one placement pass - instead of the 66-stage bitonic
     // network (50 us of this kernel's 165).  Rows of the box get one padding column so that "next cell along the minor
     // axis" never wraps into the next row.  Order inside a cell is arbitrary; the cell's sum does not depend on it
     // beyond float rounding.
-    const int mmin = swap ? sbox[2] : sbox[0], mext = (swap ? sbox[3] : sbox[1]) - mmin + 2;
-    const int Mmin = swap ? sbox[0] : sbox[2], Mext = (swap ? sbox[1] : sbox[3]) - Mmin + 1;
+    const int mmin = swap ? bymin : bxmin, mext = (swap ? bymax : bxmax) - mmin + 2;
+    const int Mmin = swap ? bxmin : bymin, Mext = (swap ? bxmax : bymax) - Mmin + 1;
     const bool counting = allow_counting && (int64_t)mext * Mext <= 4 * BM;
     if (counting) {
         constexpr int WPT = 2 * BM / NT;                       // counter words per thread in the scan
@@ -305,17 +318,18 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
             if (cpt[k] >= 0) {
                 const AxisCoord& am = swap ? cay[k] : cax[k];
                 const AxisCoord& aM = swap ? cax[k] : cay[k];
-                const int cell = aM.i0 * (swap ? ph : pw) + am.i0;
-                const unsigned q = pos[k];
-                skey[q] = ((unsigned)cell << SLOT_BITS) | q;    // records are stored in sorted order: slot = position
+                const unsigned q = pos[k];                  // records are stored in sorted order
                 sxy[q] = ((unsigned)(cay[k].i0 * psy + cax[k].i0 * psx) << 2) | (unsigned)(am.i1 > am.i0) |
                          ((unsigned)(aM.i1 > aM.i0) << 1);
-                stm[q] = am.t;
-                stM[q] = aM.t;
+                sw[q] = (float4_t){(1.0f - am.t) * (1.0f - aM.t), (1.0f - am.t) * aM.t, am.t * (1.0f - aM.t), am.t * aM.t};
                 sgrow[q] = cpt[k];
             }
         }
-        for (int i = (int)nvalid + threadIdx.x; i < BM; i += NT) skey[i] = 0xFFFFFFFFu;
+        for (int i = (int)nvalid + threadIdx.x; i < BM; i += NT) {
+            sxy[i] = PAD_XY;
+            sw[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            sgrow[i] = 0;
+        }
         __syncthreads();
     } else {
 #pragma unroll
@@ -327,11 +341,11 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
             const AxisCoord& aM = swap ? cax[k] : cay[k];       // major axis
             const int cell = aM.i0 * (swap ? ph : pw) + am.i0;
             key = ((unsigned)cell << SLOT_BITS) | (unsigned)slot;
-            sxy[slot] = ((unsigned)(cay[k].i0 * psy + cax[k].i0 * psx) << 2) | (unsigned)(am.i1 > am.i0) |
+            txy[slot] = ((unsigned)(cay[k].i0 * psy + cax[k].i0 * psx) << 2) | (unsigned)(am.i1 > am.i0) |
                         ((unsigned)(aM.i1 > aM.i0) << 1);
-            stm[slot] = am.t;
-            stM[slot] = aM.t;
-            sgrow[slot] = cpt[k];
+            ttm[slot] = am.t;
+            ttM[slot] = aM.t;
+            trow[slot] = cpt[k];
         }
         skey[slot] = key;
     }
@@ -369,17 +383,47 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
             }
         }
     }
+    // records into sorted order, through registers (the temporaries and the final layout overlap)
+    __syncthreads();
+    unsigned pxy[4];
+    float ptm[4], ptM[4];
+    int prow[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned key = skey[threadIdx.x + k * NT];
+        const bool valid = key != 0xFFFFFFFFu;
+        const int slot = key & SLOT_MASK;
+        pxy[k] = valid ? txy[slot] : PAD_XY;
+        ptm[k] = valid ? ttm[slot] : 0.f;
+        ptM[k] = valid ? ttM[slot] : 0.f;
+        prow[k] = valid ? trow[slot] : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int q = threadIdx.x + k * NT;
+        const bool valid = pxy[k] != PAD_XY;
+        sxy[q] = pxy[k];
+        sw[q] = valid ? (float4_t){(1.0f - ptm[k]) * (1.0f - ptM[k]), (1.0f - ptm[k]) * ptM[k], ptm[k] * (1.0f - ptM[k]),
+                                   ptm[k] * ptM[k]}
+                      : (float4_t){0.f, 0.f, 0.f, 0.f};
+        sgrow[q] = prow[k];
+    }
+    __syncthreads();
     }
     if (dbg_mode == 2) return;
 
-    // (3) walk: wave w owns sorted entries [256w, 256w+256), 64 at a time.  Every lane fetches ONE entry's record from
-    // LDS (cell, g_feat row, fractions); the walk reads records with v_readlane.  The g_feat values of WALK_N entries
-    // are loaded ahead of the walk of the previous WALK_N: a wave's loads, stores and atomics retire in order on one
-    // vmcnt counter, so a load issued BEHIND an atomic would wait for it (~3000 cycles under load).
+    // (3) walk: wave w owns sorted entries [256w, 256w+256), 64 at a time.  Per 64-entry block every lane fetches ONE
+    // entry's (xy, g_feat row) and the block's cell boundaries become two 64-bit scalar masks (ballots): "entry starts a
+    // new cell" and "... which is the next cell along the minor axis and shares a texel column".  The serial part per
+    // entry is then a scalar bit test, one LDS read of the lane's two weights and ONE packed FMA - the version that
+    // carried (cell, tm, tM) in registers and rebuilt the weights per entry spent ~11 VALU instructions there and was
+    // issue-bound.  The g_feat values of WALK_N entries are loaded ahead of the walk of the
+    // previous WALK_N: a wave's loads, stores and atomics retire in order on one vmcnt counter, so a load issued BEHIND an
+    // atomic would wait for it (~3000 cycles under load).
     const char* __restrict__ gcol = (const char*)(g_feat + d * 64 + lvl * 32);     // + row * 512 + c * 4 bytes
-    constexpr int DUMMY = (int)(0xFFFFFFFFu >> SLOT_BITS);     // cell of padding entries: never flushed
-    int cur_cell = -1;
-    unsigned cur_xy = 0;
+    unsigned cur_xy = PAD_XY;                  // cell being accumulated (PAD_XY: none / padding, never flushed)
+    unsigned last_xy = PAD_XY;                 // xy of the last entry of the previous block
     float acc0 = 0.f, acc1 = 0.f;
     const int e0 = wave * 256;
 
@@ -391,7 +435,7 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
     const unsigned dm_bytes = (unsigned)(swap ? psy : psx) << 2, dM_bytes = (unsigned)(swap ? psx : psy) << 2;
     char* __restrict__ gbytes = (char*)grad;
     auto flush = [&](bool lower_half_only) {
-        if (cur_cell >= 0 && cur_cell != DUMMY) {
+        if (cur_xy != PAD_XY) {
             const unsigned o0 = (cur_xy & ~3u) + lane_off + ((cur_xy & 1u) & (unsigned)hx) * dm_bytes;
             const unsigned o1 = o0 + ((cur_xy >> 1) & 1u) * dM_bytes;
             if (dbg_mode != 1) {
@@ -403,33 +447,35 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
         }
     };
 
-    struct Rec { int cell, row; unsigned xy; float tm, tM; };
-    auto fetch = [&](int blk) {
+    struct Rec { unsigned xy; int row; unsigned long long fresh, adjacent; };
+    auto fetch = [&](int blk, unsigned prev_last) {
         Rec r;
-        const unsigned k = skey[e0 + blk * WAVE + lane];
-        const bool valid = k != 0xFFFFFFFFu;
-        const int slot = k & SLOT_MASK;
-        r.cell = valid ? (int)(k >> SLOT_BITS) : DUMMY;
-        r.row = valid ? sgrow[slot] : 0;
-        r.xy = valid ? sxy[slot] : 0u;
-        r.tm = valid ? stm[slot] : 0.f;
-        r.tM = valid ? stM[slot] : 0.f;
+        const int e = e0 + blk * WAVE + lane;
+        r.xy = sxy[e];
+        r.row = sgrow[e];
+        unsigned prev = __shfl_up(r.xy, 1, WAVE);
+        if (lane == 0) prev = prev_last;
+        const bool fresh = r.xy != prev;
+        const bool adj = fresh && r.xy != PAD_XY && prev != PAD_XY && (prev & 1u) && (r.xy & ~3u) == (prev & ~3u) + dm_bytes;
+        r.fresh = __ballot(fresh);
+        r.adjacent = __ballot(adj);
         return r;
     };
 #ifndef WALK_N
 #define WALK_N 8                   // entries per load-ahead group (2 groups in flight: 2*WALK_N VGPRs)
 #endif
+    const float2_t* const wlane = (const float2_t*)sw + hx;                    // + 2 * entry
 #define LOAD_HALF(buf, rec, half)                                                             \
     _Pragma("unroll") for (int t = 0; t < WALK_N; ++t) {                                      \
         const unsigned row = (unsigned)__builtin_amdgcn_readlane((rec).row, (half) * WALK_N + t); \
         buf[t] = *(const float*)(gcol + (row * 512u + (unsigned)c * 4u));                     \
     }
-#define WALK_HALF(buf, rec, half)                                                             \
+#define WALK_HALF(buf, rec, half, ebase)                                                      \
     _Pragma("unroll") for (int t = 0; t < WALK_N; ++t) {                                      \
         const int idx = (half) * WALK_N + t;                                                  \
-        const int cell = __builtin_amdgcn_readlane((rec).cell, idx);                          \
-        if (cell != cur_cell) {                                                               \
-            if (cell == cur_cell + 1 && (cur_xy & 1u)) {                                      \
+        const float2_t w2 = wlane[2 * ((ebase) + idx)];                                       \
+        if (((rec).fresh >> idx) & 1ull) {                                                    \
+            if (((rec).adjacent >> idx) & 1ull) {                                             \
                 /* next cell along the minor axis: its first texel column is our second one - keep those sums */ \
                 flush(true);                                                                  \
                 const float s0 = __shfl_xor(acc0, 32, WAVE), s1 = __shfl_xor(acc1, 32, WAVE); \
@@ -440,37 +486,35 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
                 acc0 = 0.f;                                                                   \
                 acc1 = 0.f;                                                                   \
             }                                                                                 \
-            cur_cell = cell;                                                                  \
             cur_xy = (unsigned)__builtin_amdgcn_readlane((int)(rec).xy, idx);                 \
         }                                                                                     \
-        const float tm = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (rec).tm), idx)); \
-        const float tM = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (rec).tM), idx)); \
-        const float wm = hx ? tm : 1.0f - tm;                                                 \
-        const float g = buf[t];        /* padding entries accumulate into the DUMMY run, which is never flushed */ \
-        acc0 += g * (wm * (1.0f - tM));                                                       \
-        acc1 += g * (wm * tM);                                                                \
+        const float g = buf[t];        /* padding entries have zero weights and belong to no cell */ \
+        acc0 += g * w2[0];                                                                    \
+        acc1 += g * w2[1];                                                                    \
     }
 
     const int nblk = 256 / WAVE;
     const int ngrp = WAVE / WALK_N;                 // groups per 64-entry record block (even)
     float ga[WALK_N], gb[WALK_N];
-    Rec rec = fetch(0);
+    Rec rec = fetch(0, PAD_XY);
     LOAD_HALF(ga, rec, 0)
 #pragma unroll 1
     for (int blk = 0; blk < nblk; ++blk) {
-        if (__builtin_amdgcn_readfirstlane(rec.cell) == DUMMY) break;          // sorted: everything from here is padding
+        if ((unsigned)__builtin_amdgcn_readfirstlane((int)rec.xy) == PAD_XY) break;   // sorted: everything from here is padding
+        last_xy = (unsigned)__builtin_amdgcn_readlane((int)rec.xy, WAVE - 1);
         Rec nxt = rec;
-        if (blk + 1 < nblk) nxt = fetch(blk + 1);
+        if (blk + 1 < nblk) nxt = fetch(blk + 1, last_xy);
+        const int ebase = e0 + blk * WAVE;
 #pragma unroll
         for (int g2 = 0; g2 < ngrp; g2 += 2) {
             LOAD_HALF(gb, rec, g2 + 1)
-            WALK_HALF(ga, rec, g2)
+            WALK_HALF(ga, rec, g2, ebase)
             if (g2 + 2 < ngrp) {
                 LOAD_HALF(ga, rec, g2 + 2)
             } else if (blk + 1 < nblk) {
                 LOAD_HALF(ga, nxt, 0)
             }
-            WALK_HALF(gb, rec, g2 + 1)
+            WALK_HALF(gb, rec, g2 + 1, ebase)
         }
         rec = nxt;
     }
