@@ -150,6 +150,42 @@ def main():
         print(line, flush=True)
 
 
+def step_statistics(step, wl, n=100):
+    """SURVEY.md section 8(d) asks for median and p10 / p90 and for the forward-only rate beside the headline number.
+    Each step is bracketed by its own pair of events here (that adds a little launch gap per step, so the median sits a
+    few microseconds above ms_per_step, which times K steps back to back)."""
+    from myslam_amd import harness
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in ev:
+        a.record()
+        step()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in ev)
+    pct = {"p10": round(ts[n // 10], 4), "p50": round(ts[n // 2], 4), "p90": round(ts[(9 * n) // 10], 4), "n": n}
+
+    def fwd():
+        with torch.no_grad():
+            wl.renderer.render_batch_ray(wl.planes, wl.decoders, wl.rays_d, wl.rays_o, wl.device, wl.truncation,
+                                         gt_depth=wl.gt_depth)
+    fwd_only = None
+    try:
+        g = harness.GraphedStep(fwd, [])
+        for _ in range(10):
+            g()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            g()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / n * 1e3
+        fwd_only = {"ms": round(ms, 4), "value": wl.R * wl.S / (ms * 1e-3), "unit": "ray.samples/s",
+                    "what": "sample + render_batch_ray forward only (no_grad: nothing saved for backward), graph replay"}
+    except Exception as e:
+        fwd_only = {"error": f"{type(e).__name__}: {e}"}
+    return {"percentiles": pct, "forward_only": fwd_only}
+
+
 def run():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -225,6 +261,9 @@ def run():
     value = total_rays * wl.S / (dt / args.steps)
 
     out = None
+    extras = None
+    if rank == 0 and world == 1:
+        extras = step_statistics(step, wl)       # outside the timed region: per-step percentiles, forward-only rate
     if rank == 0:
         prof = kernel_profile(wl.step, args.profile_iters)      # eager: the HIP events sit inside the C-ABI calls
         n = wl.R * wl.S
@@ -264,6 +303,8 @@ def run():
                          "whole_step": {"algorithmic_bytes": 12304 * n, "achieved": 12304 * n / (ms_step * 1e-3) / 1e9,
                                         "frac": 12304 * n / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS}},
             "kernel_ms": {k: round(v, 4) for k, v in sorted(prof.items())},
+            "step_ms_percentiles": None if extras is None else extras["percentiles"],
+            "forward_only": None if extras is None else extras["forward_only"],
         }
     if world > 1:
         dist.barrier()
