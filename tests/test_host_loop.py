@@ -86,3 +86,31 @@ def test_loop_control_flow_on_the_oracle_backend():
     for e in est:
         R = e[:3, :3]
         assert torch.allclose(R @ R.T, torch.eye(3), atol=1e-4)
+
+
+def test_checkpoint_round_trip_in_the_reference_format(tmp_path):
+    from myslam_amd import checkpoint
+    from myslam_amd.src.networks.decoders import Decoders
+    torch.manual_seed(3)
+    dec = Decoders(learnable_beta=True)
+    gt = [torch.eye(4) for _ in range(5)]
+    est = [torch.eye(4) + 0.01 * k for k in range(5)]
+    path = str(tmp_path / "00004.tar")
+    checkpoint.save(path, dec, gt, est, [0, 4], 4)
+    raw = torch.load(path, weights_only=True)
+    assert set(raw) == {"decoder_state_dict", "gt_c2w_list", "estimate_c2w_list", "keyframe_list", "idx"}      # Logger.py:41-47
+    assert set(raw["decoder_state_dict"]) == {"beta", "linears.0.weight", "linears.0.bias", "linears.1.weight",
+                                              "linears.1.bias", "c_linears.0.weight", "c_linears.0.bias",
+                                              "c_linears.1.weight", "c_linears.1.bias", "output_linear.weight",
+                                              "output_linear.bias", "c_output_linear.weight", "c_output_linear.bias"}
+    dec2 = Decoders(learnable_beta=True)
+    ck = checkpoint.load(path, dec2)
+    assert ck["idx"] == 4 and ck["keyframe_list"] == [0, 4] and ck["estimate_c2w_list"].shape == (5, 4, 4)
+    for (k, a), (_, b) in zip(dec.state_dict().items(), dec2.state_dict().items()):
+        assert torch.equal(a, b), k
+    torch.save({"something": 1}, path)
+    try:
+        checkpoint.load(path)
+        assert False
+    except KeyError:
+        pass
