@@ -119,7 +119,14 @@ def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_handle(device):
+    """hipStream_t of the caller's current stream on `device` (the raw getter skips building a torch.cuda.Stream object:
+    7 us -> 0.3 us, and a step asks a dozen times)."""
+    if _raw_stream is not None and device.index is not None:
+        return ctypes.c_void_p(_raw_stream(device.index))
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 

@@ -34,7 +34,18 @@ def linspace01(n, device):
 
 
 def decoder_params(decoders):
-    """The 12 tensors in C-ABI order from our Decoders or the reference's (same attribute names)."""
+    """The 12 tensors in C-ABI order from our Decoders or the reference's (same attribute names).  Walking the
+    ModuleLists costs ~12 us; the list is remembered on the module and checked by identity of its first and last
+    entries (nn.Module.to() / _apply replace the Parameter objects, load_state_dict copies in place)."""
+    hit = decoders.__dict__.get("_eslam_param_list")
+    if hit is not None and hit[0] is decoders.linears[0].weight and hit[11] is decoders.c_output_linear.bias:
+        return hit
+    lst = _decoder_params_slow(decoders)
+    decoders.__dict__["_eslam_param_list"] = lst
+    return lst
+
+
+def _decoder_params_slow(decoders):
     return [decoders.linears[0].weight, decoders.linears[0].bias, decoders.linears[1].weight,
             decoders.linears[1].bias, decoders.output_linear.weight, decoders.output_linear.bias,
             decoders.c_linears[0].weight, decoders.c_linears[0].bias, decoders.c_linears[1].weight,

@@ -1,6 +1,6 @@
 """Host time per section of one eager mapping iteration (monkeypatched timers, no cProfile overhead)."""
 import sys, time, collections, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from myslam_amd import harness, ops, _hip
 acc = collections.defaultdict(float)
 def wrap(obj, name, label=None):
@@ -14,7 +14,7 @@ wrap(ops.RenderFn, 'forward', 'RenderFn.forward'); wrap(ops.RenderFn, 'backward'
 wrap(ops.MappingLossFn, 'forward', 'Loss.forward'); wrap(ops.MappingLossFn, 'backward', 'Loss.backward')
 wrap(_hip, 'make_planes'); wrap(_hip, 'make_decoders'); wrap(ops, 'decoder_params'); wrap(_hip, 'stream_handle')
 lib = _hip.lib()
-for fn in ('eslam_render_fwd', 'eslam_render_bwd', 'eslam_sample_z', 'eslam_importance_z', 'eslam_loss_reduce', 'eslam_loss_grad', 'eslam_ray_order'):
+for fn in ('eslam_render_fwd', 'eslam_render_bwd', 'eslam_sample_z_all', 'eslam_loss_value', 'eslam_loss_grad', 'eslam_ray_order'):
     f = getattr(lib, fn)
     def mk(f, fn):
         def g(*a):

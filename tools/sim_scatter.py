@@ -1,7 +1,7 @@
 """CPU simulation of the plane-gradient scatter: how many atomic flushes different merge strategies need
 on the bench workload (room0, 4096x64).  Pure numpy; no GPU."""
 import sys, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from myslam_amd import scene as scn, synth
 from oracle import eslam_oracle as orc
 

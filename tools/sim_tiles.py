@@ -2,7 +2,7 @@
 Morton-ordered ray list?  Counts unique cells per tile (2 x 256-B atomic instr each, what scatter_sort_kernel does)
 and unique texel-row-pairs with x-carry.  Pure numpy."""
 import sys, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from myslam_amd import scene as scn, synth
 from oracle import eslam_oracle as orc
 sc = scn.make_scene('room0')
