@@ -268,6 +268,25 @@ int eslam_loss_value(const float* depth, const float* rgb, const float* sdf, con
                      const float* weights5_host, const uint8_t* ray_mask, float* scratch, float* acc, float* loss,
                      eslam_stream_t stream);
 
+/* Block-sparse exchange of the flat gradient buffer between ray-sharded ranks ("reducing only
+ * touched tiles"; myslam_amd/parallel.py).  A block is 32 consecutive floats = one texel's channels in a channels_last
+ * plane.  eslam_blocks_touched: touched[b] = 1 if block b of `flat` holds a non-zero.  After the ranks have agreed on the
+ * union (an all-reduce(MAX) of `touched`, then idx = its non-zero positions, ascending): eslam_blocks_pack gathers
+ * blocks idx[0..n_idx) and the dense `tail` (decoder gradients) into buf [n_idx*32 + n_tail]; eslam_blocks_unpack
+ * writes the all-reduced buf back.  flat and buf 16-byte aligned.                                                   */
+int eslam_blocks_touched(const float* flat, int64_t n_blocks, uint8_t* touched, eslam_stream_t stream);
+/* The same bitmap from the sample positions instead of the gradients - available right after the forward pass, so the
+ * ranks can agree on the union while the backward pass runs.  channels_last planes only (one block = one texel);
+ * block_base_host[12] = index of each plane's first block in the flat buffer; touched [n_blocks] is cleared here.
+ * Marks every texel eslam_render_bwd will add to (a superset of the non-zero blocks).                           */
+int eslam_mark_touched(const eslam_plane_t* planes, const float* bound6_host, const float* rays_o, const float* rays_d,
+                       const float* z_vals, int R, int S, const int64_t* block_base_host, int64_t n_blocks,
+                       uint8_t* touched, eslam_stream_t stream);
+int eslam_blocks_pack(const float* flat, const int64_t* idx, int64_t n_idx, const float* tail, int64_t n_tail, float* buf,
+                      eslam_stream_t stream);
+int eslam_blocks_unpack(float* flat, const int64_t* idx, int64_t n_idx, float* tail, int64_t n_tail, const float* buf,
+                        eslam_stream_t stream);
+
 /* Per-kernel device timing for bench.py's roofline line (HIP events recorded on the launch stream around each
  * kernel while enabled; adds nothing to the launch path when disabled).  Usage: enable(1); run one iteration;
  * synchronise the stream; read(ms) -> elapsed milliseconds of the LAST launch of each kernel, -1 if it did not run. */

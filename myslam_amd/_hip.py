@@ -67,6 +67,10 @@ SIGNATURES = {
     "eslam_pose_to_c2w_bwd": (_i, [_vp, _vp, _i, _vp, _vp]),
     "eslam_tracking_mask": (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp]),
     "eslam_keep_best": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "eslam_mark_touched": (_i, [_PP, _BP, _vp, _vp, _vp, _i, _i, _vp, _i64, _vp, _vp]),
+    "eslam_blocks_touched": (_i, [_vp, _i64, _vp, _vp]),
+    "eslam_blocks_pack": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "eslam_blocks_unpack": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "eslam_keyframe_overlap": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _f, _f, _f, _f, _i, _vp, _vp]),
 }
 

@@ -154,3 +154,84 @@ extern "C" int eslam_keep_best(const float* loss, const float* pose, int n, floa
     hipLaunchKernelGGL(keep_best_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, loss, pose, n, best, best_pose);
     return eslam_check_launch("keep_best_kernel");
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Block-sparse gradient exchange of the ray-sharded mapper (myslam_amd/parallel.py FlatGrads.all_reduce_compact):
+// which 128-byte blocks (one texel's 32 channels in a channels_last plane) of the flat gradient buffer are non-zero,
+// and gather / scatter of the blocks every rank agreed to exchange.  8 lanes x float4 per block.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void blocks_touched_kernel(const float* __restrict__ flat, int64_t n_blocks,
+                                                             uint8_t* __restrict__ touched) {
+    const int sub = threadIdx.x & 7;
+    for (int64_t b = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); b < n_blocks; b += (int64_t)gridDim.x * 32) {
+        const float4_t v = *(const float4_t*)(flat + b * 32 + sub * 4);
+        int nz = (v[0] != 0.0f) | (v[1] != 0.0f) | (v[2] != 0.0f) | (v[3] != 0.0f);
+        nz |= __shfl_xor(nz, 1, WAVE);
+        nz |= __shfl_xor(nz, 2, WAVE);
+        nz |= __shfl_xor(nz, 4, WAVE);
+        if (sub == 0) touched[b] = (uint8_t)nz;
+    }
+}
+
+template <bool PACK>
+__global__ __launch_bounds__(256) void blocks_move_kernel(float* __restrict__ flat, const int64_t* __restrict__ idx,
+                                                          int64_t n_idx, float* __restrict__ tail, int64_t n_tail,
+                                                          float* __restrict__ buf) {
+    const int sub = threadIdx.x & 7;
+    const int64_t stride = (int64_t)gridDim.x * 32;
+    for (int64_t i = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); i < n_idx; i += stride) {
+        float4_t* a = (float4_t*)(flat + idx[i] * 32 + sub * 4);
+        float4_t* b = (float4_t*)(buf + i * 32 + sub * 4);
+        if (PACK) *b = *a;
+        else *a = *b;
+    }
+    float* tbuf = buf + n_idx * 32;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_tail; i += (int64_t)gridDim.x * 256) {
+        if (PACK) tbuf[i] = tail[i];
+        else tail[i] = tbuf[i];
+    }
+}
+
+extern "C" int eslam_blocks_touched(const float* flat, int64_t n_blocks, uint8_t* touched, eslam_stream_t stream) {
+    if (n_blocks <= 0) return 0;
+    if (!flat || !touched || ((uintptr_t)flat & 15)) {
+        eslam_set_error("eslam_blocks_touched: null or unaligned argument");
+        return 1;
+    }
+    const int64_t want = (n_blocks + 31) / 32;
+    hipLaunchKernelGGL(blocks_touched_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0,
+                       (hipStream_t)stream, flat, n_blocks, touched);
+    return eslam_check_launch("blocks_touched_kernel");
+}
+
+static int blocks_move(bool pack, float* flat, const int64_t* idx, int64_t n_idx, float* tail, int64_t n_tail, float* buf,
+                       eslam_stream_t stream) {
+    if (n_idx < 0 || n_tail < 0) {
+        eslam_set_error("eslam_blocks_pack/unpack: negative size");
+        return 1;
+    }
+    if (n_idx == 0 && n_tail == 0) return 0;
+    if (!buf || (n_idx > 0 && (!flat || !idx)) || (n_tail > 0 && !tail) || ((uintptr_t)flat & 15) || ((uintptr_t)buf & 15)) {
+        eslam_set_error("eslam_blocks_pack/unpack: null or unaligned argument");
+        return 1;
+    }
+    const int64_t want = (n_idx + 31) / 32 > (n_tail + 255) / 256 ? (n_idx + 31) / 32 : (n_tail + 255) / 256;
+    const dim3 grid((unsigned)(want < 4096 ? (want > 0 ? want : 1) : 4096));
+    if (pack)
+        hipLaunchKernelGGL(blocks_move_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, flat, idx, n_idx, tail,
+                           n_tail, buf);
+    else
+        hipLaunchKernelGGL(blocks_move_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, flat, idx, n_idx, tail,
+                           n_tail, buf);
+    return eslam_check_launch("blocks_move_kernel");
+}
+
+extern "C" int eslam_blocks_pack(const float* flat, const int64_t* idx, int64_t n_idx, const float* tail, int64_t n_tail,
+                                 float* buf, eslam_stream_t stream) {
+    return blocks_move(true, (float*)flat, idx, n_idx, (float*)tail, n_tail, buf, stream);
+}
+
+extern "C" int eslam_blocks_unpack(float* flat, const int64_t* idx, int64_t n_idx, float* tail, int64_t n_tail,
+                                   const float* buf, eslam_stream_t stream) {
+    return blocks_move(false, flat, idx, n_idx, tail, n_tail, (float*)buf, stream);
+}

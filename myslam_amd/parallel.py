@@ -13,6 +13,9 @@ Identical optimiser steps on every rank then keep the replicas in sync without a
 The flat buffer is also what RenderFn.backward scatters into (ops.grad_sink), so no copy sits between the backward
 kernels and the collective.  Tracking (pose-only, needs a global median) is not sharded: "replicas only".
 """
+import ctypes
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -55,6 +58,59 @@ class FlatGrads:
     def all_reduce(self, group=None, async_op=False):
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
+    def all_reduce_compact(self, n_block_elems, group=None, block=32):
+        """Sum over ranks, exchanging only the blocks of `block` floats that are non-zero on SOME rank.
+
+        The first n_block_elems floats (the planes: one block = one texel's 32 channels in channels_last planes) are
+        block-sparse after a mapping backward - a frame's rays touch 4-25 % of the texels, and
+        ranks that render the same keyframe window touch nearly the same ones - so the 27-70 MB dense all-reduce, which
+        is what bounds ray-sharded scaling over xGMI, becomes three steps:
+          1. all-reduce(MAX) of one byte per block (212 KB for room0)  -> the union of touched blocks, same on all ranks
+          2. gather the union's blocks + the dense tail (decoder / beta gradients) into one buffer, all-reduce(SUM)
+          3. scatter the blocks back.
+        `nonzero()` needs the union's size on the host: one stream synchronisation per step, which the collectives -
+        issued eagerly between the captured phases anyway - tolerate.  Plain tensor ops on purpose: the identical code
+        runs under gloo on the CPU in the tests, so the multi-rank logic is verified without multi-GPU hardware."""
+        if n_block_elems % block:
+            raise RuntimeError("all_reduce_compact: the block-sparse prefix must be a multiple of the block size")
+        rows = self.flat[:n_block_elems].view(-1, block)
+        on_gpu = self.flat.is_cuda and self.flat.dtype == torch.float32 and block == 32
+        if on_gpu:                 # one launch for the bitmap
+            lib, dev = _hip.lib(), self.flat.device
+            touched = torch.empty(rows.shape[0], dtype=torch.uint8, device=dev)
+            with _hip.on_device(dev):
+                _hip.check(lib.eslam_blocks_touched(_hip.ptr(self.flat), rows.shape[0], _hip.ptr(touched),
+                                                    _hip.stream_handle(dev)), "eslam_blocks_touched")
+        else:
+            touched = (torch.count_nonzero(rows, dim=1) > 0).to(torch.uint8)
+        dist.all_reduce(touched, op=dist.ReduceOp.MAX, group=group)
+        idx = touched.nonzero().squeeze(1)                     # host sync: the union's size
+        return self.exchange_blocks(idx, n_block_elems, group, block)
+
+    def exchange_blocks(self, idx, n_block_elems, group=None, block=32):
+        """Steps 2 and 3 of all_reduce_compact for a union `idx` (ascending block indices, identical on every rank)."""
+        rows = self.flat[:n_block_elems].view(-1, block)
+        tail = self.flat[n_block_elems:]
+        k = idx.numel() * block
+        if self.flat.is_cuda and self.flat.dtype == torch.float32 and block == 32:
+            lib, dev = _hip.lib(), self.flat.device
+            buf = torch.empty(k + tail.numel(), device=dev)
+            with _hip.on_device(dev):
+                _hip.check(lib.eslam_blocks_pack(_hip.ptr(self.flat), _hip.ptr(idx), idx.numel(), _hip.ptr(tail),
+                                                 tail.numel(), _hip.ptr(buf), _hip.stream_handle(dev)), "eslam_blocks_pack")
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+            with _hip.on_device(dev):
+                _hip.check(lib.eslam_blocks_unpack(_hip.ptr(self.flat), _hip.ptr(idx), idx.numel(), _hip.ptr(tail),
+                                                   tail.numel(), _hip.ptr(buf), _hip.stream_handle(dev)),
+                           "eslam_blocks_unpack")
+        else:
+            buf = torch.cat([rows.index_select(0, idx).reshape(-1), tail])
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+            rows.index_copy_(0, idx, buf[:k].view(-1, block))
+            tail.copy_(buf[k:])
+        self.last_exchange = (int(buf.numel()) * buf.element_size() + rows.shape[0], self.flat.numel() * self.flat.element_size())
+        return self.last_exchange
+
     def assign(self):
         """Point every parameter's .grad at its view (after the collective)."""
         for p, v in zip(self.params, self.views):
@@ -74,7 +130,7 @@ class ShardedMapper:
     broadcast.  With fused_zero_grad it leaves the flat buffer zero, which saves the 27-70 MB
     fill of the next iteration; under capture() it becomes a third graph (capturable=True is required for that)."""
 
-    def __init__(self, workload, group=None, optimizer=None):
+    def __init__(self, workload, group=None, optimizer=None, compact=None):
         from . import losses
         self.wl = workload
         self.group = group
@@ -86,6 +142,19 @@ class ShardedMapper:
             self.params = self.params + [beta]
         self.grads = FlatGrads(self.params)
         self.optimizer = optimizer
+        # gradient exchange: block-sparse (FlatGrads.all_reduce_compact) unless ESLAM_DP_COMPACT=0 / compact=False
+        self.compact = (os.environ.get("ESLAM_DP_COMPACT", "1") != "0") if compact is None else bool(compact)
+        self._n_plane_elems = sum(p.numel() for p in self.params[:12])
+        # With channels_last planes the union of touched texels is known from the sample positions right after the
+        # forward pass (eslam_mark_touched): the ranks agree on it - and the host learns its size - while the backward
+        # pass is still running, so the exchange itself follows the backward without a bubble.
+        planes = self.params[:12]
+        self._can_mark = bool(self.compact and planes[0].is_cuda and
+                              all(p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last) for p in planes))
+        if self._can_mark:
+            self._touched = torch.zeros(self._n_plane_elems // 32, dtype=torch.uint8, device=workload.device)
+            self._block_base = (ctypes.c_int64 * 12)(*[self.grads.offsets[i] // 32 for i in range(12)])
+            self._side = torch.cuda.Stream(device=workload.device)
         self.acc = torch.zeros(16, device=workload.device)
         self._out = None
         self._graphs = None
@@ -99,6 +168,14 @@ class ShardedMapper:
                                                  gt_depth=wl.gt_depth)
         depth, color, sdf, z = self._out
         ops.loss_reduce(depth, color, sdf, z, wl.gt_depth, wl.gt_color, wl.truncation, None, self.acc)
+        if self._can_mark:
+            arr, _ = _hip.make_planes(tuple([p.detach() for p in grp] for grp in wl.planes))
+            with _hip.on_device(wl.device):
+                _hip.check(_hip.lib().eslam_mark_touched(arr, _hip.make_bound(ops.bound_to_host(wl.scene.bound)),
+                                                         _hip.ptr(wl.rays_o.detach()), _hip.ptr(wl.rays_d.detach()),
+                                                         _hip.ptr(z), wl.R, wl.S, self._block_base,
+                                                         self._touched.numel(), _hip.ptr(self._touched),
+                                                         _hip.stream_handle(wl.device)), "eslam_mark_touched")
 
     def phase_b(self):
         wl = self.wl
@@ -127,13 +204,33 @@ class ShardedMapper:
             self.grads.clean = True
 
     def _eager(self):
-        self.phase_a()
+        return self._run(self.phase_a, self.phase_b, self.phase_c if self.optimizer is not None else None)
+
+    def _run(self, run_a, run_b, run_c):
+        """One iteration: phases a / b / c (eager calls or graph replays) with the collectives between them."""
+        run_a()
         dist.all_reduce(self.acc, op=dist.ReduceOp.SUM, group=self.group)
-        self.phase_b()
-        self.grads.all_reduce(self.group)
+        ev = None
+        if self._can_mark:
+            dist.all_reduce(self._touched, op=dist.ReduceOp.MAX, group=self.group)
+            ev = torch.cuda.Event()
+            ev.record()
+        run_b()                                    # enqueued before the host waits for the union below
+        if self._can_mark:
+            cur = torch.cuda.current_stream(self.wl.device)
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ev)
+                idx = self._touched.nonzero().squeeze(1)        # synchronises the SIDE stream only
+            cur.wait_stream(self._side)
+            idx.record_stream(cur)
+            self.grads.exchange_blocks(idx, self._n_plane_elems, self.group)
+        elif self.compact:
+            self.grads.all_reduce_compact(self._n_plane_elems, self.group)
+        else:
+            self.grads.all_reduce(self.group)
         self.grads.assign()
-        if self.optimizer is not None:
-            self.phase_c()
+        if run_c is not None:
+            run_c()
         return self.loss
 
     def capture(self, warmup=3):
@@ -164,11 +261,4 @@ class ShardedMapper:
         if self._graphs is None:
             return self._eager()
         ga, gb, gc = self._graphs
-        ga.replay()
-        dist.all_reduce(self.acc, op=dist.ReduceOp.SUM, group=self.group)
-        gb.replay()
-        self.grads.all_reduce(self.group)
-        self.grads.assign()
-        if gc is not None:
-            gc.replay()
-        return self.loss
+        return self._run(ga.replay, gb.replay, gc.replay if gc is not None else None)

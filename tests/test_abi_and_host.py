@@ -166,7 +166,7 @@ def _free_port():
     return p
 
 
-def _dp_worker(rank, world, port, ret):
+def _dp_worker(rank, world, port, ret, compact):
     """One gloo rank: oracle forward on its ray shard, two-phase loss with all-reduced denominators, gradients
     all-reduced through parallel.FlatGrads - the same sequence parallel.ShardedMapper runs on the GPU."""
     import torch.distributed as dist
@@ -212,7 +212,12 @@ def _dp_worker(rank, world, port, ret):
     grads = torch.autograd.grad(local, plist)
     for v, g in zip(fg.views, grads):
         v.copy_(g)
-    fg.all_reduce()
+    if compact:      # block-sparse exchange: only the texel rows some rank touched, plus the dense decoder tail
+        sent, dense = fg.all_reduce_compact(sum(p.numel() for p in plist[:12]))
+        if rank == 0:
+            ret["exchange"] = (sent, dense)
+    else:
+        fg.all_reduce()
     fg.assign()
     total = local.detach().clone()
     dist.all_reduce(total)
@@ -223,13 +228,14 @@ def _dp_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_ray_sharded_data_parallel_equals_single_process():
+@pytest.mark.parametrize("world,compact", [(2, False), (2, True), (3, True)])
+def test_ray_sharded_data_parallel_equals_single_process(world, compact):
     import torch.multiprocessing as mp
     from tests.test_oracle_golden import run_oracle
     mgr = mp.Manager()
     ret = mgr.dict()
     port = _free_port()
-    mp.spawn(_dp_worker, args=(2, port, ret), nprocs=2, join=True)
+    mp.spawn(_dp_worker, args=(world, port, ret, compact), nprocs=world, join=True)
     fx = hp.load("room0_200x40_zero15")
     ref = run_oracle(fx, torch.float64)
     assert abs(ret["loss"] - float(ref["loss"])) <= 1e-10 * abs(float(ref["loss"]))
@@ -241,3 +247,6 @@ def test_ray_sharded_data_parallel_equals_single_process():
                                if g.dim() == 4 else g.reshape(-1).numpy() for g in ref_list])
     assert ret["strides_ok"]
     assert np.abs(ret["flat"] - flat_ref).max() <= 1e-9 * np.abs(flat_ref).max()
+    if compact:
+        sent, dense = ret["exchange"]
+        assert sent < 0.5 * dense, (sent, dense)          # 200 rays touch a small part of the 27 MB of planes

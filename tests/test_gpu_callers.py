@@ -135,3 +135,74 @@ def test_tracking_loss_masked_equals_compacted():
     assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(lb))
     for a, b in zip(ga, gb):
         assert hp.rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 1e-6
+
+
+def test_block_sparse_exchange_kernels():
+    """eslam_blocks_touched / pack / unpack against the tensor ops parallel.FlatGrads.all_reduce_compact uses on the CPU."""
+    import ctypes
+    from myslam_amd import _hip
+    dev = _dev()
+    lib = _hip.lib()
+    g = torch.Generator().manual_seed(5)
+    n_blocks, n_tail = 10007, 2693
+    rows = torch.randn(n_blocks, 32, generator=g)
+    rows[torch.rand(n_blocks, generator=g) < 0.8] = 0.0            # 80 % empty blocks
+    rows[5, :] = 0.0
+    rows[5, 31] = -0.0                                             # a negative zero is still zero
+    rows[7, :] = 0.0
+    rows[7, 17] = 1e-30                                            # a single tiny value marks the block
+    flat = torch.cat([rows.reshape(-1), torch.randn(n_tail, generator=g)]).to(dev)
+    touched = torch.empty(n_blocks, dtype=torch.uint8, device=dev)
+    st = _hip.stream_handle(dev)
+    _hip.check(lib.eslam_blocks_touched(_hip.ptr(flat), n_blocks, _hip.ptr(touched), st), "touched")
+    ref_t = (torch.count_nonzero(rows, dim=1) > 0)
+    assert torch.equal(touched.cpu().bool(), ref_t) and not bool(touched[5]) and bool(touched[7])
+    idx = touched.nonzero().squeeze(1)
+    tail = flat[n_blocks * 32:]
+    buf = torch.empty(idx.numel() * 32 + n_tail, device=dev)
+    _hip.check(lib.eslam_blocks_pack(_hip.ptr(flat), _hip.ptr(idx), idx.numel(), _hip.ptr(tail), n_tail, _hip.ptr(buf), st), "pack")
+    assert torch.equal(buf.cpu(), torch.cat([rows[ref_t].reshape(-1), flat[n_blocks * 32:].cpu()]))
+    before = flat.clone()
+    buf.mul_(3.0)
+    _hip.check(lib.eslam_blocks_unpack(_hip.ptr(flat), _hip.ptr(idx), idx.numel(), _hip.ptr(tail), n_tail, _hip.ptr(buf), st), "unpack")
+    assert torch.equal(flat, before * 3.0)                         # untouched blocks are zero either way
+    # empty union, empty tail
+    z = torch.zeros(64, device=dev)
+    t2 = torch.empty(2, dtype=torch.uint8, device=dev)
+    _hip.check(lib.eslam_blocks_touched(_hip.ptr(z), 2, _hip.ptr(t2), st), "touched")
+    assert t2.tolist() == [0, 0]
+    assert lib.eslam_blocks_pack(_hip.ptr(z), None, 0, None, 0, _hip.ptr(z), st) == 0
+
+
+@pytest.mark.parametrize("scene,zero_frac", [("room0", 0.0), ("toy", 0.2)])
+def test_marked_texels_contain_every_block_the_backward_touches(scene, zero_frac):
+    """eslam_mark_touched (from sample positions, after the forward) must be a superset of the non-zero 128-byte blocks
+    of the plane gradients (eslam_blocks_touched after the backward) - the block-sparse exchange relies on it."""
+    import ctypes
+    from myslam_amd import harness, ops, _hip
+    from myslam_amd.parallel import FlatGrads
+    dev = _dev()
+    wl = harness.make_workload(scene, 3000, 40, 8, device=dev, zero_frac=zero_frac)
+    params = wl.plane_list + ops.decoder_params(wl.decoders) + [wl.decoders.beta]
+    fg = FlatGrads(params)
+    depth, color, sdf, z = wl.renderer.render_batch_ray(wl.planes, wl.decoders, wl.rays_d, wl.rays_o, dev, wl.truncation,
+                                                        gt_depth=wl.gt_depth)
+    n_blocks = sum(p.numel() for p in wl.plane_list) // 32
+    marked = torch.empty(n_blocks, dtype=torch.uint8, device=dev)
+    base = (ctypes.c_int64 * 12)(*[fg.offsets[i] // 32 for i in range(12)])
+    arr, _ = _hip.make_planes(tuple([p.detach() for p in grp] for grp in wl.planes))
+    st = _hip.stream_handle(dev)
+    _hip.check(_hip.lib().eslam_mark_touched(arr, _hip.make_bound(ops.bound_to_host(wl.scene.bound)), _hip.ptr(wl.rays_o),
+                                             _hip.ptr(wl.rays_d), _hip.ptr(z), wl.R, wl.S, base, n_blocks,
+                                             _hip.ptr(marked), st), "eslam_mark_touched")
+    with ops.grad_sink(fg):
+        ((depth * wl._cot[0]).sum() + (color * wl._cot[1]).sum() + (sdf * wl._cot[2]).sum()).backward()
+    nz = torch.empty(n_blocks, dtype=torch.uint8, device=dev)
+    _hip.check(_hip.lib().eslam_blocks_touched(_hip.ptr(fg.flat), n_blocks, _hip.ptr(nz), st), "eslam_blocks_touched")
+    torch.cuda.synchronize()
+    assert int(nz.sum()) > 100
+    assert int((nz.bool() & ~marked.bool()).sum()) == 0, "a texel received gradient without being marked"
+    # ... and not wildly larger: samples behind the surface have transmittance exactly 0 in float32, so the colour planes'
+    # texels there are visited but receive exact zeros - the marked set is up to ~3x the non-zero set, still a small
+    # fraction of the 212 k blocks
+    assert int(marked.sum()) <= 4 * int(nz.sum()) and int(marked.sum()) < 0.3 * n_blocks
