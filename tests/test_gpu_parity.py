@@ -378,6 +378,71 @@ def test_mesher_eval_points_against_oracle():
     assert hp.rel_err(got2[inside2].numpy(), ref[inside2].numpy()) <= RTOL
 
 
+def _two_rank_worker(rank, world, port, ret):
+    """One of two processes sharing the single GPU of the box, talking over gloo (RCCL refuses two ranks on one device):
+    the complete ShardedMapper path - marking, bitmap agreement, side-stream union, pack / all-reduce / unpack, graphs."""
+    import os
+    import torch.distributed as dist
+    from myslam_amd import harness
+    from myslam_amd.parallel import ShardedMapper
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        wl = harness.make_workload("room0", 600, 32, 8, device=dev, planes="synth", seed=rank, zero_frac=0.1)
+        wl.renderer.perturb = False
+        out = {}
+        for label, compact in (("dense", False), ("sparse", True)):
+            m = ShardedMapper(wl, compact=compact)
+            assert m._can_mark == compact
+            loss = m.step()
+            torch.cuda.synchronize()
+            out[label] = (float(loss), m.grads.flat.cpu().numpy().copy())
+            if compact:
+                out["exchange"] = m.grads.last_exchange
+                m.capture(warmup=1)
+                for _ in range(2):
+                    loss = m.step()
+                torch.cuda.synchronize()
+                out["graph"] = (float(loss), m.grads.flat.cpu().numpy().copy())
+        if rank == 0:
+            ret.update(out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_mapper_two_ranks_on_one_gpu():
+    import socket
+    import torch.multiprocessing as mp
+    from myslam_amd import harness, ops
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_two_rank_worker, args=(2, port, ret), nprocs=2, join=True)
+    # the unsharded reference: both ranks' rays in one batch through the plain autograd path
+    dev = _dev()
+    w0 = harness.make_workload("room0", 600, 32, 8, device=dev, planes="synth", seed=0, zero_frac=0.1)
+    w1 = harness.make_workload("room0", 600, 32, 8, device=dev, planes="synth", seed=1, zero_frac=0.1)
+    w0.renderer.perturb = False
+    for name in ("rays_o", "rays_d", "gt_depth", "gt_color"):
+        setattr(w0, name, torch.cat([getattr(w0, name), getattr(w1, name)], 0).contiguous())
+    w0.R = int(w0.rays_o.shape[0])
+    loss = w0.step()
+    params = w0.plane_list + ops.decoder_params(w0.decoders) + [w0.decoders.beta]      # order of the flat buffer
+    flat_ref = torch.cat([p.grad.detach().permute(0, 2, 3, 1).reshape(-1) if p.dim() == 4 else p.grad.detach().reshape(-1)
+                          for p in params]).cpu().numpy()
+    for label in ("dense", "sparse", "graph"):
+        lv, flat = ret[label]
+        assert abs(lv - float(loss)) <= 1e-5 * abs(float(loss)), label
+        assert hp.rel_err(flat, flat_ref) <= 2e-5, label
+    sent, dense = ret["exchange"]
+    assert sent < 0.25 * dense, (sent, dense)
+
+
 def test_graft_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
