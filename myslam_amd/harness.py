@@ -55,6 +55,7 @@ class Workload:
         self.gt_depth = gd[inside].contiguous()
         self.gt_color = gc[inside].contiguous()
         self.R = int(self.rays_o.shape[0])
+        self._one = torch.ones((), device=dev)
         # fixed random numbers / cotangents for the reproducible (test) paths
         self._rand = (torch.from_numpy(synth.hash_uniform((self.R, self.S), 90_000)).to(dev),
                       torch.from_numpy(synth.hash_uniform((self.R, n_strat), 90_001)).to(dev),
@@ -101,7 +102,7 @@ class Workload:
         depth, color, sdf, z = self.renderer.render_batch_ray(self.planes, self.decoders, self.rays_d, self.rays_o,
                                                               self.device, self.truncation, gt_depth=self.gt_depth)
         loss = losses.mapping_loss(depth, color, sdf, z, self.gt_depth, self.gt_color, self.truncation)
-        loss.backward()
+        loss.backward(gradient=self._one)          # a cached 1.0 instead of autograd's ones_like(loss) fill per step
         return loss
 
 
