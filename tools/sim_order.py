@@ -1,21 +1,14 @@
 """CPU simulation of the ray ORDER used for bundling in the scatter: for each candidate order of the bench rays
 (room0, 4096x64), bundles of 32 consecutive rays x 12 planes -> number of distinct cells (= flush count before the
 column carry) and the share of (bundle, plane) boxes too large for the in-LDS counting sort (> 8192 padded bins)."""
-import os, sys, numpy as np, torch
+import os, sys, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from myslam_amd import scene as scn, synth
-from oracle import eslam_oracle as orc
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _cpu_samples import bench_samples
 
-sc = scn.make_scene('room0')
 R, ns, ni = 4096, 56, 8
 S = ns + ni
-depth_img = torch.from_numpy(synth.depth_image(sc.H, sc.W, 10))[None]
-color_img = torch.from_numpy(synth.color_image(sc.H, sc.W, 12))[None]
-idx = torch.from_numpy(synth.hash_randint(sc.H * sc.W, (R,), 50_000))
-c2w = scn.center_pose(sc)[None]
-ro, rd, gd, gc = orc.rays_from_pixels(idx, 0, sc.H, 0, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, c2w, depth_img, color_img)
-z = orc.depth_guided_z(gd, ns, ni, 0.06, torch.from_numpy(synth.hash_uniform((R, S), 90_000)))
-pn = orc.normalize_points(ro[:, None, :] + rd[:, None, :] * z[..., None], sc.bound).reshape(R, S, 3).numpy()
+sc, idx, ro, rd, z, pn = bench_samples(R, ns, ni)
 
 def spread(v, bits):
     out = np.zeros_like(v, dtype=np.uint64)
@@ -29,7 +22,7 @@ def spread2(v, bits):
         out |= ((v >> b) & 1).astype(np.uint64) << (2 * b)
     return out
 
-p1 = (ro + rd / rd.norm(dim=1, keepdim=True)).numpy()
+p1 = ro + rd / np.linalg.norm(rd, axis=1, keepdims=True)
 
 def morton3(bits):
     lo, hi = p1.min(0), p1.max(0)

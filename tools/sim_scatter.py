@@ -1,22 +1,17 @@
 """CPU simulation of the plane-gradient scatter: how many atomic flushes different merge strategies need
 on the bench workload (room0, 4096x64).  Pure numpy; no GPU."""
-import sys, numpy as np, torch
+import sys, numpy as np
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
-from myslam_amd import scene as scn, synth
-from oracle import eslam_oracle as orc
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.abspath(__file__)))
+from _cpu_samples import bench_samples
 
-sc = scn.make_scene('room0')
 R, ns, ni = 4096, 56, 8
 S = ns + ni
-depth_img = torch.from_numpy(synth.depth_image(sc.H, sc.W, 10))[None]
-color_img = torch.from_numpy(synth.color_image(sc.H, sc.W, 12))[None]
-idx = torch.from_numpy(synth.hash_randint(sc.H * sc.W, (R,), 50_000))
-c2w = scn.center_pose(sc)[None]
-ro, rd, gd, gc = orc.rays_from_pixels(idx, 0, sc.H, 0, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, c2w, depth_img, color_img)
-t_rand = torch.from_numpy(synth.hash_uniform((R, S), 90_000))
-z = orc.depth_guided_z(gd, ns, ni, 0.06, t_rand)
-pts = ro[:, None, :] + rd[:, None, :] * z[..., None]
-pn = orc.normalize_points(pts, sc.bound).reshape(R, S, 3).numpy()
+sc, _idx, _ro, _rd, _z, pn = bench_samples(R, ns, ni)
+class _T:
+    def __init__(self, a): self.a = a
+    def numpy(self): return self.a
+idx, rd = _T(_idx), _T(_rd)
 names = ['geo-coarse', 'geo-fine', 'col-coarse', 'col-fine']
 tot = {}
 for d in range(2):

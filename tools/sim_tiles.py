@@ -1,20 +1,16 @@
 """How many atomic flushes does the bundle scatter issue under different (rays x samples) tilings of the
 Morton-ordered ray list?  Counts unique cells per tile (2 x 256-B atomic instr each, what scatter_sort_kernel does)
 and unique texel-row-pairs with x-carry.  Pure numpy."""
-import sys, numpy as np, torch
-sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
-from myslam_amd import scene as scn, synth
-from oracle import eslam_oracle as orc
-sc = scn.make_scene('room0')
+import os, sys, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _cpu_samples import bench_samples
 R, ns, ni = 4096, 56, 8
 S = ns + ni
-depth_img = torch.from_numpy(synth.depth_image(sc.H, sc.W, 10))[None]
-color_img = torch.from_numpy(synth.color_image(sc.H, sc.W, 12))[None]
-idx = torch.from_numpy(synth.hash_randint(sc.H * sc.W, (R,), 50_000))
-c2w = scn.center_pose(sc)[None]
-ro, rd, gd, gc = orc.rays_from_pixels(idx, 0, sc.H, 0, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, c2w, depth_img, color_img)
-z = orc.depth_guided_z(gd, ns, ni, 0.06, torch.from_numpy(synth.hash_uniform((R, S), 90_000)))
-pn = orc.normalize_points(ro[:, None, :] + rd[:, None, :] * z[..., None], sc.bound).reshape(R, S, 3).numpy()
+sc, _idx, _ro, _rd, _z, pn = bench_samples(R, ns, ni)
+class _T:      # minimal stand-ins for the two tensors the code below reads with .numpy()
+    def __init__(self, a): self.a = a
+    def numpy(self): return self.a
+ro, rd = _T(_ro), _T(_rd)
 def part(v):
     v = v.astype(np.uint32) & 0x3FF
     v = (v | (v << 16)) & 0x030000FF; v = (v | (v << 8)) & 0x0300F00F; v = (v | (v << 4)) & 0x030C30C3; v = (v | (v << 2)) & 0x09249249
