@@ -144,6 +144,10 @@ def ray_order_async(rays_o, rays_d):
     return perm, side
 
 
+import os as _os
+_FWD_USES_ORDER = _os.environ.get("ESLAM_FWD_ORDER", "0") == "1"
+
+
 class RenderFn(torch.autograd.Function):
     """depth, rgb, sdf = RenderFn.apply(rays_o, rays_d, z_vals, bound6, beta, order, *12 planes, *12 decoder params)
 
@@ -174,7 +178,8 @@ class RenderFn(torch.autograd.Function):
         with _hip.on_device(dev):
             _hip.check(lib.eslam_render_fwd(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(rays_o),
                                             _hip.ptr(rays_d), _hip.ptr(z_vals), R, S, _hip.ptr(depth), _hip.ptr(rgb),
-                                            _hip.ptr(sdf), _hip.ptr(raw_rgb), _hip.ptr(feat), _hip.ptr(order),
+                                            _hip.ptr(sdf), _hip.ptr(raw_rgb), _hip.ptr(feat),
+                                            _hip.ptr(order) if _FWD_USES_ORDER else None,
                                             _hip.stream_handle(dev)), "eslam_render_fwd")
         if needs:
             ctx.bound6 = bound6

@@ -206,3 +206,30 @@ def test_marked_texels_contain_every_block_the_backward_touches(scene, zero_frac
     # texels there are visited but receive exact zeros - the marked set is up to ~3x the non-zero set, still a small
     # fraction of the 212 k blocks
     assert int(marked.sum()) <= 4 * int(nz.sum()) and int(marked.sum()) < 0.3 * n_blocks
+
+
+@pytest.mark.parametrize("cameras,R", [(1, 4096), (1, 77), (3, 3000), (1, 9000)])
+def test_ray_order_is_a_permutation_and_groups_neighbours(cameras, R):
+    """eslam_ray_order: a permutation of every chunk of 8192 rays, for one origin (2-D Hilbert key of the direction) and
+    several (3-D Morton key); consecutive rays of the order point in nearby directions."""
+    from myslam_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(cameras * 1000 + R)
+    org = torch.randn(cameras, 3, generator=g)
+    cam = torch.randint(cameras, (R,), generator=g)
+    ro = org[cam].to(dev)
+    d = torch.randn(R, 3, generator=g) * 0.35
+    d[:, 2] = -1.0                                              # a pinhole-like fan of directions
+    rd = d.to(dev)
+    perm, side = ops.ray_order_async(ro, rd)
+    torch.cuda.current_stream().wait_stream(side)
+    p = perm.cpu().long()
+    for lo in range(0, R, 8192):                                # chunks are ordered independently
+        hi = min(R, lo + 8192)
+        assert torch.equal(torch.sort(p[lo:hi]).values, torch.arange(lo, hi))
+    if cameras == 1 and R >= 1000:
+        dn = torch.nn.functional.normalize(d, dim=1)
+        n1 = min(R, 8192)
+        step_sorted = (dn[p[1:n1]] - dn[p[:n1 - 1]]).norm(dim=1).mean()
+        step_given = (dn[1:n1] - dn[:n1 - 1]).norm(dim=1).mean()
+        assert float(step_sorted) < 0.1 * float(step_given)
