@@ -148,6 +148,14 @@ import os as _os
 _FWD_USES_ORDER = _os.environ.get("ESLAM_FWD_ORDER", "0") == "1"
 
 
+def join_ray_order(device):
+    """Make the current stream wait for the ray-ordering side stream.  RenderFn joins it in its backward; a caller that
+    captures forward and backward into SEPARATE hipGraphs must join inside the forward's capture (parallel.py)."""
+    side = _side_streams.get(torch.device(device).index)
+    if side is not None:
+        torch.cuda.current_stream(device).wait_stream(side)
+
+
 class RenderFn(torch.autograd.Function):
     """depth, rgb, sdf = RenderFn.apply(rays_o, rays_d, z_vals, bound6, beta, order, *12 planes, *12 decoder params)
 
@@ -174,7 +182,11 @@ class RenderFn(torch.autograd.Function):
         order = None
         if order_in is not None:
             order, side = order_in
-            torch.cuda.current_stream(dev).wait_stream(side)
+            if _FWD_USES_ORDER:
+                torch.cuda.current_stream(dev).wait_stream(side)
+                side = None
+            # otherwise only the backward needs the order: the ordering kernel (side stream) is joined there, and the
+            # forward kernel starts as soon as the samplers are done
         with _hip.on_device(dev):
             _hip.check(lib.eslam_render_fwd(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(rays_o),
                                             _hip.ptr(rays_d), _hip.ptr(z_vals), R, S, _hip.ptr(depth), _hip.ptr(rgb),
@@ -183,7 +195,10 @@ class RenderFn(torch.autograd.Function):
                                             _hip.stream_handle(dev)), "eslam_render_fwd")
         if needs:
             ctx.bound6 = bound6
+            ctx.order_stream = side if order_in is not None else None
             ctx.save_for_backward(rays_o, rays_d, z_vals, sdf, raw_rgb, feat, order, beta, *planes, *params)
+        elif order_in is not None and not _FWD_USES_ORDER:
+            torch.cuda.current_stream(dev).wait_stream(side)      # nobody will join it later
         return depth, rgb, sdf
 
     @staticmethod
@@ -194,6 +209,9 @@ class RenderFn(torch.autograd.Function):
         R, S = z_vals.shape
         dev = rays_o.device
         lib = _hip.lib()
+        if getattr(ctx, "order_stream", None) is not None:
+            torch.cuda.current_stream(dev).wait_stream(ctx.order_stream)      # join the ordering kernel
+            ctx.order_stream = None
         need = ctx.needs_input_grad
         need_planes = any(need[6:18])
         need_rays = need[0] or need[1]

@@ -168,6 +168,7 @@ class ShardedMapper:
                                                  gt_depth=wl.gt_depth)
         depth, color, sdf, z = self._out
         ops.loss_reduce(depth, color, sdf, z, wl.gt_depth, wl.gt_color, wl.truncation, None, self.acc)
+        ops.join_ray_order(wl.device)              # forward and backward are separate graphs: join the fork in this one
         if self._can_mark:
             arr, _ = _hip.make_planes(tuple([p.detach() for p in grp] for grp in wl.planes))
             with _hip.on_device(wl.device):
