@@ -26,10 +26,20 @@ from . import losses, ops, optim
 from .slam import HipBackend, Slam
 
 
+class _EagerReplay:
+    """replay() = call the iteration directly: the sync-free formulation without hipGraphs (use_graphs=False)."""
+
+    def __init__(self, fn):
+        self.replay = fn
+
+
 class GraphedSlam(Slam):
-    def __init__(self, sc, cfg=None, device="cuda:0", seed=0, warmup=2):
+    def __init__(self, sc, cfg=None, device="cuda:0", seed=0, warmup=2, use_graphs=True):
+        """use_graphs=False keeps the sync-free iterations (masks, device-side median / best pose, in-place optimiser
+        reset) but issues them eagerly - for hosts that cannot capture graphs; about 2x the plain eager loop."""
         super().__init__(sc, cfg, device, backend=HipBackend(sc, device), seed=seed)
         self.warmup = warmup
+        self.use_graphs = bool(use_graphs)
         self._bound6 = ops.bound_to_host(sc.bound)
         # persistent Parameters: the graphs hold their addresses (the reference re-wraps the same storages per frame)
         for grp in self.all_planes:
@@ -45,6 +55,8 @@ class GraphedSlam(Slam):
     # ------------------------------------------------------------------------------------------------------------
     def _capture(self, fn, reset):
         """Warm up `fn` on a side stream (creates optimiser state outside the graph), reset, capture."""
+        if not self.use_graphs:
+            return _EagerReplay(fn)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         side = torch.cuda.Stream()

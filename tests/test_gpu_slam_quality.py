@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 def _run(backend_kind, n_frames, cfg, seed=0):
     from myslam_amd import eval_ate, scene as scn, slam, synthscene
     sc = scn.make_scene("toy")
-    if backend_kind in ("hip", "graph"):
+    if backend_kind in ("hip", "graph", "syncfree"):
         dev, backend = torch.device("cuda:0"), None
     else:
         from tests.oracle_backend import OracleBackend
@@ -24,9 +24,9 @@ def _run(backend_kind, n_frames, cfg, seed=0):
     frames = synthscene.make_sequence(sc, n_frames, device=dev)
     torch.manual_seed(seed)
     t0 = time.perf_counter()
-    if backend_kind == "graph":
+    if backend_kind in ("graph", "syncfree"):
         from myslam_amd.slam_graph import GraphedSlam
-        s = GraphedSlam(sc, cfg, device=dev, seed=seed)
+        s = GraphedSlam(sc, cfg, device=dev, seed=seed, use_graphs=(backend_kind == "graph"))
     else:
         s = slam.Slam(sc, cfg, device=dev, backend=backend, seed=seed)
     est = s.run(frames)
@@ -83,3 +83,8 @@ def test_graph_captured_loop_matches_eager_loop():
     assert abs(q_g["psnr"] - q_e["psnr"]) < 1.0
     assert abs(q_g["depth_l1"] - q_e["depth_l1"]) < 0.3 * max(q_g["depth_l1"], q_e["depth_l1"]) + 0.002
     assert abs(ate_g["rmse"] - ate_e["rmse"]) < 0.5 * max(ate_g["rmse"], ate_e["rmse"]) + 0.002
+    # the same sync-free iterations issued eagerly (no graphs)
+    ate_s, q_s, st_s = _run("syncfree", n_frames, cfg)
+    print(f"sync-free eager: ATE rmse {ate_s['rmse']*100:.2f} cm, PSNR {q_s['psnr']:.2f} dB, depth L1 {q_s['depth_l1']*100:.2f} cm, {st_s}")
+    assert st_s["tracking_iters"] == st_e["tracking_iters"] and "graphs" not in st_s
+    assert ate_s["rmse"] < 0.02 and abs(q_s["psnr"] - q_e["psnr"]) < 1.0

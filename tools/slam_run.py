@@ -1,7 +1,7 @@
 """BASELINE.json configs[2] in synthetic form: the tracking + mapping loop (myslam_amd/slam.py) on the HIP path over an
 analytic RGB-D sequence in the Replica room0 geometry (680 x 1200 images, room0 bound and planes, the reference's
 Replica iteration counts and pixel budgets), reporting ATE, render quality and where the time goes.
-    python tools/slam_run.py [n_frames] [iters_first] [eager|graph]
+    python tools/slam_run.py [n_frames] [iters_first] [eager|graph|syncfree]
 """
 import sys, time, torch
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
@@ -18,9 +18,9 @@ frames = synthscene.make_sequence(sc, n_frames, device=dev)
 torch.cuda.synchronize()
 print(f"sequence of {n_frames} frames {sc.H}x{sc.W} rendered in {time.perf_counter()-t0:.1f} s", flush=True)
 torch.manual_seed(0)
-if mode == 'graph':
+if mode in ('graph', 'syncfree'):
     from myslam_amd.slam_graph import GraphedSlam
-    s = GraphedSlam(sc, cfg, device=dev, seed=0)
+    s = GraphedSlam(sc, cfg, device=dev, seed=0, use_graphs=(mode == 'graph'))
 else:
     s = slam.Slam(sc, cfg, device=dev, seed=0)
 marks = []
