@@ -47,6 +47,8 @@ SIGNATURES = {
     "eslam_importance_z": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "eslam_sample_z_all": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "eslam_render_fwd": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "eslam_render_fwd_loss": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _BP, _vp,
+                                   _vp, _vp, _vp, _vp]),
     "eslam_render_fwd_lowp": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "eslam_ray_order": (_i, [_vp, _vp, _i, _vp, _vp]),
     "eslam_bwd_workspace_bytes": (_i64, [_i64]),

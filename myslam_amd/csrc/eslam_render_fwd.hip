@@ -4,11 +4,27 @@
 // One wave64 = one ray (render) or one tile of 64 points (decode); 4 waves per workgroup share an LDS copy of
 // the decoder weights.  See eslam_decode_tile.h for the lane roles and the MFMA operand plan.
 #include "eslam_decode_tile.h"
+#include "eslam_loss_final.h"
 
 // ---------------------------------------------------------------------------------------------------------
 // render: replaces reference src/utils/Renderer.py:136-147 (+ decoders.py:64-146, common.py:204-218)
 // ---------------------------------------------------------------------------------------------------------
-template <bool CL, bool SAVE>
+// LOSS: the kernel also forms the sums of the callers' loss (src/Mapper.py:110-144,337-346) from the values it has in
+// registers anyway - per sample the region of z against gt_depth and the squared SDF error, per ray the depth and colour
+// errors - reduces them per workgroup and finishes acc [16] and the loss value with the ticket scheme of eslam_loss_value:
+// one launch less per iteration (14 us), and sdf / depth / rgb are not read back for it.
+struct LossIn {
+    const float* gt_depth;
+    const float* gt_color;
+    const uint8_t* ray_mask;
+    float* scratch;
+    float* acc;
+    float* loss;
+    Trunc tr;
+    LossW w;
+};
+
+template <bool CL, bool SAVE, bool LOSS>
 #ifndef FWD_WAVES
 #define FWD_WAVES 2            // waves per SIMD the gather kernels are compiled for: with one plane of loads in flight
                                // ahead of the FMAs the forward kernel needs 195 VGPRs; 2 waves/SIMD measured fastest
@@ -19,7 +35,8 @@ __global__ __launch_bounds__(256, FWD_WAVES) void render_fwd_kernel(const PlaneS
                                                          const float* __restrict__ z_vals, int R, int S,
                                                          float* __restrict__ depth_out, float* __restrict__ rgb_out,
                                                          float* __restrict__ sdf_out, float* __restrict__ raw_rgb_out,
-                                                         float* __restrict__ feat_out, const int* __restrict__ perm) {
+                                                         float* __restrict__ feat_out, const int* __restrict__ perm,
+                                                         const LossIn li) {
     __shared__ __attribute__((aligned(16))) float wlds[2 * DEC_LDS];
     stage_decoder_weights(wlds, dec, threadIdx.x, blockDim.x);
     __syncthreads();
@@ -27,6 +44,9 @@ __global__ __launch_bounds__(256, FWD_WAVES) void render_fwd_kernel(const PlaneS
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int r = lane & 15, q = lane >> 4;
+    float lv[A_COUNT];                     // LOSS: this lane's share of the accumulators
+#pragma unroll
+    for (int k = 0; k < A_COUNT; ++k) lv[k] = 0.0f;
     // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one, MI355X_MICROARCH.md).  Give every
     // XCD a contiguous run of the ray order, so that rays through neighbouring pixels - which read the same texels -
     // are resident on CUs behind the same L2.  Placement only affects speed: the grid has 8*cpx blocks, every logical
@@ -34,8 +54,12 @@ __global__ __launch_bounds__(256, FWD_WAVES) void render_fwd_kernel(const PlaneS
     const int cpx = gridDim.x >> 3;
     const int lblock = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
     const int slot = lblock * 4 + wave;
-    if (slot >= R) return;
+    if (!LOSS && slot >= R) return;
+    if (slot < R) {                        // (LOSS: idle waves still take part in the workgroup's reduction below)
     const int ray = perm ? perm[slot] : slot;
+    const float gtd = LOSS ? li.gt_depth[ray] : 0.0f;
+    const bool in_batch = LOSS ? (li.ray_mask ? li.ray_mask[ray] != 0 : true) : false;
+    const bool has_depth = in_batch && gtd > 0.0f;
 
     const float ox = rays_o[ray * 3 + 0], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
     const float dx = rays_d[ray * 3 + 0], dy = rays_d[ray * 3 + 1], dz = rays_d[ray * 3 + 2];
@@ -103,12 +127,41 @@ __global__ __launch_bounds__(256, FWD_WAVES) void render_fwd_kernel(const PlaneS
         acc_g += wave_sum(w * cg);
         acc_b += wave_sum(w * cb);
         trans_in *= __shfl(pin, 63, WAVE);
+        if (LOSS && valid && has_depth) {              // Mapper.py:124-140
+            const int reg = sdf_region(z, gtd, li.tr);
+            if (reg == 0) { lv[A_N_FRONT] += 1.0f; const float e = sdf - 1.0f; lv[A_S_FRONT] += e * e; }
+            else if (reg == 1) { lv[A_N_CENTER] += 1.0f; const float e = (z + sdf * li.tr.t) - gtd; lv[A_S_CENTER] += e * e; }
+            else if (reg == 2) { lv[A_N_TAIL] += 1.0f; const float e = (z + sdf * li.tr.t) - gtd; lv[A_S_TAIL] += e * e; }
+        }
     }
     if (lane == 0) {
         depth_out[ray] = acc_depth;
         rgb_out[ray * 3 + 0] = acc_r;
         rgb_out[ray * 3 + 1] = acc_g;
         rgb_out[ray * 3 + 2] = acc_b;
+        if (LOSS) {                                    // Mapper.py:343,346
+            if (has_depth) { const float e = gtd - acc_depth; lv[A_N_DEPTH] += 1.0f; lv[A_S_DEPTH] += e * e; }
+            if (in_batch) {
+                const float er = li.gt_color[3 * ray] - acc_r, eg = li.gt_color[3 * ray + 1] - acc_g,
+                            eb = li.gt_color[3 * ray + 2] - acc_b;
+                lv[A_S_COLOR] += (er * er + eg * eg) + eb * eb;
+                lv[A_N_COLOR] += 3.0f;
+            }
+        }
+    }
+    }
+    if (LOSS) {
+        __shared__ float red[4][A_COUNT];
+#pragma unroll
+        for (int k = 0; k < A_COUNT; ++k) {
+            const float t = wave_sum(lv[k]);
+            if (lane == 0) red[wave][k] = t;
+        }
+        __syncthreads();
+        float tot = 0.0f;
+        if (threadIdx.x < A_COUNT)
+            tot = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        loss_finalize(tot, li.scratch, li.acc, li.w, li.loss);
     }
 }
 
@@ -193,21 +246,21 @@ static Bound make_bound(const float* b6) {
     return b;
 }
 
-extern "C" int eslam_render_fwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
-                                const float* rays_o, const float* rays_d, const float* z_vals, int R, int S,
-                                float* depth, float* rgb, float* sdf, float* raw_rgb, float* feat,
-                                const int32_t* ray_order, eslam_stream_t stream) {
+static int render_fwd_common(const char* who, const eslam_plane_t* planes, const eslam_decoders_t* dec,
+                             const float* bound6_host, const float* rays_o, const float* rays_d, const float* z_vals,
+                             int R, int S, float* depth, float* rgb, float* sdf, float* raw_rgb, float* feat,
+                             const int32_t* ray_order, const LossIn* li, eslam_stream_t stream) {
     if (R <= 0) return 0;
     if (S <= 0 || S > ESLAM_MAX_SAMPLES) {
-        eslam_set_error("eslam_render_fwd: S=%d outside [1,%d]", S, ESLAM_MAX_SAMPLES);
+        eslam_set_error("%s: S=%d outside [1,%d]", who, S, ESLAM_MAX_SAMPLES);
         return 1;
     }
     if (!planes || !dec || !bound6_host || !rays_o || !rays_d || !z_vals || !depth || !rgb || !sdf) {
-        eslam_set_error("eslam_render_fwd: null argument");
+        eslam_set_error("%s: null argument", who);
         return 1;
     }
     if ((raw_rgb == nullptr) != (feat == nullptr)) {
-        eslam_set_error("eslam_render_fwd: raw_rgb and feat must both be given or both be NULL");
+        eslam_set_error("%s: raw_rgb and feat must both be given or both be NULL", who);
         return 1;
     }
     if (eslam_validate_planes(planes, 0, NPL)) return 1;
@@ -219,17 +272,56 @@ extern "C" int eslam_render_fwd(const eslam_plane_t* planes, const eslam_decoder
     const int nblocks = (R + 3) / 4;
     dim3 grid(((nblocks + 7) / 8) * 8), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(CLv, SV)                                                                                             \
-    hipLaunchKernelGGL((render_fwd_kernel<CLv, SV>), grid, block, 0, st, ps, *dec, bnd, rays_o, rays_d, z_vals, R, \
-                       S, depth, rgb, sdf, raw_rgb, feat, (const int*)ray_order)
+    const LossIn none = {};
+#define LAUNCH(CLv, SV, LS)                                                                                             \
+    hipLaunchKernelGGL((render_fwd_kernel<CLv, SV, LS>), grid, block, 0, st, ps, *dec, bnd, rays_o, rays_d, z_vals, R, \
+                       S, depth, rgb, sdf, raw_rgb, feat, (const int*)ray_order, LS ? *li : none)
     eslam_prof_begin(PROF_RENDER_FWD, st);
-    if (cl && save) LAUNCH(true, true);
-    else if (cl) LAUNCH(true, false);
-    else if (save) LAUNCH(false, true);
-    else LAUNCH(false, false);
+    if (li) {
+        if (cl && save) LAUNCH(true, true, true);
+        else if (cl) LAUNCH(true, false, true);
+        else if (save) LAUNCH(false, true, true);
+        else LAUNCH(false, false, true);
+    } else {
+        if (cl && save) LAUNCH(true, true, false);
+        else if (cl) LAUNCH(true, false, false);
+        else if (save) LAUNCH(false, true, false);
+        else LAUNCH(false, false, false);
+    }
 #undef LAUNCH
     eslam_prof_end(PROF_RENDER_FWD, st);
     return eslam_check_launch("render_fwd_kernel");
+}
+
+extern "C" int eslam_render_fwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
+                                const float* rays_o, const float* rays_d, const float* z_vals, int R, int S,
+                                float* depth, float* rgb, float* sdf, float* raw_rgb, float* feat,
+                                const int32_t* ray_order, eslam_stream_t stream) {
+    return render_fwd_common("eslam_render_fwd", planes, dec, bound6_host, rays_o, rays_d, z_vals, R, S, depth, rgb, sdf,
+                             raw_rgb, feat, ray_order, nullptr, stream);
+}
+
+extern "C" int eslam_render_fwd_loss(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
+                                     const float* rays_o, const float* rays_d, const float* z_vals, int R, int S,
+                                     float* depth, float* rgb, float* sdf, float* raw_rgb, float* feat,
+                                     const int32_t* ray_order, const float* gt_depth, const float* gt_color,
+                                     double truncation, const float* weights5_host, const uint8_t* ray_mask,
+                                     float* scratch, float* acc, float* loss, eslam_stream_t stream) {
+    if (!gt_depth || !gt_color || !weights5_host || !scratch || !acc) {
+        eslam_set_error("eslam_render_fwd_loss: null loss argument");
+        return 1;
+    }
+    if (R <= 0) {
+        eslam_set_error("eslam_render_fwd_loss: empty batch");
+        return 1;
+    }
+    LossIn li;
+    li.gt_depth = gt_depth; li.gt_color = gt_color; li.ray_mask = ray_mask;
+    li.scratch = scratch; li.acc = acc; li.loss = loss;
+    li.tr = make_trunc(truncation);
+    li.w = LossW{weights5_host[0], weights5_host[1], weights5_host[2], weights5_host[3], weights5_host[4]};
+    return render_fwd_common("eslam_render_fwd_loss", planes, dec, bound6_host, rays_o, rays_d, z_vals, R, S, depth, rgb,
+                             sdf, raw_rgb, feat, ray_order, &li, stream);
 }
 
 extern "C" int eslam_decode_fwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,

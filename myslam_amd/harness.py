@@ -5,6 +5,7 @@ src/ESLAM.py:201-210), decoders with default nn.Linear init, beta = 10, camera a
 rotation, depth image ~ U(0.5, 2.5) m, colour ~ U(0,1).  Rays come from get_samples on the whole image followed
 by the caller-side AABB pre-filter of reference src/Mapper.py:322-332, exactly as a mapping iteration does.
 """
+import os
 from types import SimpleNamespace
 
 import torch
@@ -13,6 +14,9 @@ from . import losses, ops, scene as scn, synth
 from .src.common import get_samples_at
 from .src.networks.decoders import Decoders
 from .src.utils.Renderer import Renderer
+
+
+_SEPARATE_LOSS = os.environ.get("ESLAM_SEPARATE_LOSS", "0") == "1"
 
 
 class Workload:
@@ -99,9 +103,18 @@ class Workload:
         """One mapping iteration minus the optimiser step: render, loss, backward."""
         for p in self.params():
             p.grad = None
-        depth, color, sdf, z = self.renderer.render_batch_ray(self.planes, self.decoders, self.rays_d, self.rays_o,
-                                                              self.device, self.truncation, gt_depth=self.gt_depth)
-        loss = losses.mapping_loss(depth, color, sdf, z, self.gt_depth, self.gt_color, self.truncation)
+        # the loss sums ride in the forward kernel's epilogue (eslam_render_fwd_loss): one launch less than a separate
+        # eslam_loss_value; ESLAM_SEPARATE_LOSS=1 restores the two-call form the reference's loop has
+        if _SEPARATE_LOSS:
+            depth, color, sdf, z = self.renderer.render_batch_ray(self.planes, self.decoders, self.rays_d, self.rays_o,
+                                                                  self.device, self.truncation, gt_depth=self.gt_depth)
+            loss = losses.mapping_loss(depth, color, sdf, z, self.gt_depth, self.gt_color, self.truncation)
+        else:
+            depth, color, sdf, z, pre = self.renderer.render_batch_ray_with_loss(
+                self.planes, self.decoders, self.rays_d, self.rays_o, self.device, self.truncation, self.gt_depth,
+                self.gt_color, losses.MAPPING_W)
+            loss = losses.mapping_loss(depth, color, sdf, z, self.gt_depth, self.gt_color, self.truncation,
+                                       precomputed=pre)
         loss.backward(gradient=self._one)          # a cached 1.0 instead of autograd's ones_like(loss) fill per step
         return loss
 

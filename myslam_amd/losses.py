@@ -12,10 +12,18 @@ MAPPING_W = (5.0, 200.0, 10.0, 0.1, 5.0)       # w_sdf_fs, w_sdf_center, w_sdf_t
 TRACKING_W = (10.0, 200.0, 50.0, 1.0, 5.0)
 
 
-def mapping_loss(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights=MAPPING_W, ray_mask=None):
+def mapping_loss(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights=MAPPING_W, ray_mask=None,
+                 precomputed=None):
     """Mapper.py:337-346: SDF + depth terms over rays with gt_depth > 0, colour over all rays.
     ray_mask (bool [R], optional): restrict every term to these rays - the AABB pre-filter of Mapper.py:322-332 kept
-    as a mask, so the batch keeps a static shape and no boolean index forces a host sync."""
+    as a mask, so the batch keeps a static shape and no boolean index forces a host sync.
+    precomputed: the ops.fused_loss context the forward pass ran under (Renderer.render_batch_ray_with_loss): sums and
+    value come from the forward kernel, only the backward is left to do here."""
+    if precomputed is not None:
+        if precomputed.acc is None:
+            raise RuntimeError("mapping_loss: the fused_loss context has not seen a forward pass")
+        return ops.MappingLossFn.apply(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights,
+                                       precomputed.ray_mask, None, (precomputed.acc, precomputed.value))
     return ops.MappingLossFn.apply(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights, ray_mask, None,
                                    None)
 

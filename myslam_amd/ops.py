@@ -150,6 +150,29 @@ def ray_order_async(rays_o, rays_d):
 _FWD_USES_ORDER = os.environ.get("ESLAM_FWD_ORDER", "0") == "1"
 
 
+_fused_loss = None
+
+
+class fused_loss:
+    """Context manager: the next RenderFn.forward also forms the sums of the callers' loss in the forward kernel's
+    epilogue (eslam_render_fwd_loss) - one launch less than eslam_loss_value.  After the call `.acc` [16] and `.value` [1]
+    are set; hand them to losses.mapping_loss(..., precomputed=ctx) so that it skips its own reduction.
+    Mapping-style loss only (the tracker's outlier mask depends on the rendered depth itself)."""
+
+    def __init__(self, gt_depth, gt_color, truncation, weights5, ray_mask=None):
+        self.gt_depth, self.gt_color, self.truncation, self.weights5, self.ray_mask = gt_depth, gt_color, truncation, weights5, ray_mask
+        self.acc = self.value = None
+
+    def __enter__(self):
+        global _fused_loss
+        self._prev, _fused_loss = _fused_loss, self
+        return self
+
+    def __exit__(self, *a):
+        global _fused_loss
+        _fused_loss = self._prev
+
+
 def join_ray_order(device):
     """Make the current stream wait for the ray-ordering side stream.  RenderFn joins it in its backward; a caller that
     captures forward and backward into SEPARATE hipGraphs must join inside the forward's capture (parallel.py)."""
@@ -189,12 +212,31 @@ class RenderFn(torch.autograd.Function):
                 side = None
             # otherwise only the backward needs the order: the ordering kernel (side stream) is joined there, and the
             # forward kernel starts as soon as the samplers are done
+        fl = _fused_loss
         with _hip.on_device(dev):
-            _hip.check(lib.eslam_render_fwd(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(rays_o),
-                                            _hip.ptr(rays_d), _hip.ptr(z_vals), R, S, _hip.ptr(depth), _hip.ptr(rgb),
-                                            _hip.ptr(sdf), _hip.ptr(raw_rgb), _hip.ptr(feat),
-                                            _hip.ptr(order) if _FWD_USES_ORDER else None,
-                                            _hip.stream_handle(dev)), "eslam_render_fwd")
+            if fl is None:
+                _hip.check(lib.eslam_render_fwd(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(rays_o),
+                                                _hip.ptr(rays_d), _hip.ptr(z_vals), R, S, _hip.ptr(depth), _hip.ptr(rgb),
+                                                _hip.ptr(sdf), _hip.ptr(raw_rgb), _hip.ptr(feat),
+                                                _hip.ptr(order) if _FWD_USES_ORDER else None,
+                                                _hip.stream_handle(dev)), "eslam_render_fwd")
+            else:
+                _hip.require_gpu_f32("gt_depth", fl.gt_depth)
+                _hip.require_gpu_f32("gt_color", fl.gt_color)
+                mask = fl.ray_mask
+                if mask is not None:
+                    mask = _c(mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8))
+                fl.acc, fl.value = torch.empty(16, device=dev), torch.empty(1, device=dev)
+                w5 = (ctypes.c_float * 5)(*[float(v) for v in fl.weights5])
+                _hip.check(lib.eslam_render_fwd_loss(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(rays_o),
+                                                     _hip.ptr(rays_d), _hip.ptr(z_vals), R, S, _hip.ptr(depth),
+                                                     _hip.ptr(rgb), _hip.ptr(sdf), _hip.ptr(raw_rgb), _hip.ptr(feat),
+                                                     _hip.ptr(order) if _FWD_USES_ORDER else None,
+                                                     _hip.ptr(_c(fl.gt_depth)), _hip.ptr(_c(fl.gt_color)),
+                                                     float(fl.truncation), w5, _hip.ptr(mask),
+                                                     _hip.ptr(_loss_scratch(dev)), _hip.ptr(fl.acc), _hip.ptr(fl.value),
+                                                     _hip.stream_handle(dev)), "eslam_render_fwd_loss")
+                fl.ray_mask_u8 = mask
         if needs:
             ctx.bound6 = bound6
             ctx.order_stream = side if order_in is not None else None
@@ -559,7 +601,10 @@ class MappingLossFn(torch.autograd.Function):
         args = [_c(t.detach()) for t in (depth, rgb, sdf, z_vals, gt_depth, gt_color)]
         loss = torch.empty(1, device=dev)
         w = (ctypes.c_float * 5)(*[float(v) for v in weights5])
-        if acc is None and group is None:
+        if isinstance(acc, tuple):
+            acc, value = acc                     # both already formed by the forward kernel (ops.fused_loss)
+            loss = value
+        elif acc is None and group is None:
             # single GPU: sums, set sizes and the value in one launch, no pre-zeroed accumulator
             acc = torch.empty(16, device=dev)
             with _hip.on_device(dev):

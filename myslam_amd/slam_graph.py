@@ -179,8 +179,9 @@ class GraphedSlam(Slam):
             ro, rd, gd, gc = be.get_samples(0, sc.H, 0, sc.W, pixs, sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, c2ws_, depths,
                                             colors, dev)
             keep = ops.prefilter(ro, rd, gd, self._bound6, False)                     # Mapper.py:322-328, as a mask
-            depth, color, sdf, z = be.render_batch_ray(self.all_planes, self.decoders, rd, ro, self.truncation, gd)
-            loss = losses.mapping_loss(depth, color, sdf, z, gd, gc, self.truncation, cfg.mapping_w, ray_mask=keep)
+            depth, color, sdf, z, pre = be.renderer.render_batch_ray_with_loss(
+                self.all_planes, self.decoders, rd, ro, dev, self.truncation, gd, gc, cfg.mapping_w, ray_mask=keep)
+            loss = losses.mapping_loss(depth, color, sdf, z, gd, gc, self.truncation, cfg.mapping_w, precomputed=pre)
             st.opt.zero_grad()
             loss.backward()
             st.opt.step()

@@ -47,6 +47,15 @@ class Renderer(object):
                                              *ops.decoder_params(decoders))
         return depth, rgb, sdf, z_vals
 
+    def render_batch_ray_with_loss(self, all_planes, decoders, rays_d, rays_o, device, truncation, gt_depth, gt_color,
+                                   weights, ray_mask=None, _rand=None):
+        """render_batch_ray + the sums of the mapping loss (src/Mapper.py:337-346) formed in the forward kernel's
+        epilogue.  Returns (depth, rgb, sdf, z_vals, pre); pass `pre` as losses.mapping_loss(..., precomputed=pre)."""
+        with ops.fused_loss(gt_depth, gt_color, truncation, weights, ray_mask) as pre:
+            depth, rgb, sdf, z_vals = self.render_batch_ray(all_planes, decoders, rays_d, rays_o, device, truncation,
+                                                            gt_depth=gt_depth, _rand=_rand)
+        return depth, rgb, sdf, z_vals, pre
+
     def sdf2alpha(self, sdf, beta=10):
         """Renderer.py:149-153 (kept for callers; the kernels fuse it)."""
         return 1. - torch.exp(-beta * torch.sigmoid(-sdf * beta))

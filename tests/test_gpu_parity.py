@@ -57,8 +57,17 @@ def run_hip(fx, channels_last=True, rays_grad=True, fused_loss=False):
     gd = torch.from_numpy(fx["gt_depth"]).to(dev)
     gc = torch.from_numpy(fx["gt_color"]).to(dev)
     tr = float(fx["truncation"])
-    depth, color, sdf, z = renderer.render_batch_ray(planes, dec, rd, ro, dev, tr, gt_depth=gd, _rand=rand)
     kind = str(fx["loss_kind"])
+    if fused_loss == "forward":     # loss sums formed in the forward kernel's epilogue (mapping loss only)
+        from myslam_amd import losses
+        assert kind == "mapping"
+        depth, color, sdf, z, pre = renderer.render_batch_ray_with_loss(planes, dec, rd, ro, dev, tr, gd, gc,
+                                                                        losses.MAPPING_W, _rand=rand)
+        loss = losses.mapping_loss(depth, color, sdf, z, gd, gc, tr, precomputed=pre)
+        loss.backward()
+        torch.cuda.synchronize()
+        return dict(depth=depth, color=color, sdf=sdf, z=z, loss=loss, ro=ro, rd=rd, dec=dec, planes=planes, pre=pre)
+    depth, color, sdf, z = renderer.render_batch_ray(planes, dec, rd, ro, dev, tr, gt_depth=gd, _rand=rand)
     if fused_loss:
         from myslam_amd import losses
         loss = (losses.mapping_loss if kind == "mapping" else losses.tracking_loss)(depth, color, sdf, z, gd, gc, tr)
@@ -128,6 +137,21 @@ def test_full_gradients_vs_oracle(case):
     assert hp.rel_err(r["rd"].grad.cpu().numpy(), o["rd"].grad.numpy()) <= RTOL
     if bool(fx["beta_is_param"]):
         assert hp.rel_err(r["dec"].beta.grad.cpu().numpy(), o["beta"].grad.numpy()) <= RTOL
+
+
+@pytest.mark.parametrize("case", ["room0_200x32", "room0_200x40_zero15", "room0_4096x64", "scene0000_8192x96_zero10"])
+def test_loss_sums_in_the_forward_epilogue(case):
+    """eslam_render_fwd_loss: the forward kernel forms the loss sums itself; value, accumulators and every gradient must
+    match the reference fixture and the separate eslam_loss_value launch."""
+    from myslam_amd import ops
+    fx = hp.load(case)
+    r = run_hip(fx, fused_loss="forward")
+    check_against_fixture(fx, r)
+    acc_sep = ops.loss_reduce(r["depth"], r["color"], r["sdf"], r["z"], torch.from_numpy(fx["gt_depth"]).to(_dev()),
+                              torch.from_numpy(fx["gt_color"]).to(_dev()), float(fx["truncation"]))
+    a, b = r["pre"].acc.cpu().numpy()[:10], acc_sep.cpu().numpy()[:10]
+    assert np.array_equal(a[[0, 1, 2, 6, 9]], b[[0, 1, 2, 6, 9]])                  # set sizes: exact
+    assert hp.rel_err(a, b) <= 1e-5                                               # error sums: summation order only
 
 
 def test_tracking_mode_pose_gradients_only():
