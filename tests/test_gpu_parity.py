@@ -363,9 +363,11 @@ def test_sharded_mapper_one_rank_rccl():
         for _ in range(6):
             lb = wb.step()
             ob.step()
-        assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb))
+        # (run-to-run differences in the last bits of the gradients - float atomics - are amplified by Adam for
+        # near-zero gradients: lr * dg / eps per step; hence 3e-4, not the 1e-5 of a single backward)
+        assert abs(float(la) - float(lb)) <= 1e-4 * abs(float(lb))
         for a, b in zip(wa.params(), wb.params()):
-            assert hp.rel_err(a.detach().cpu().numpy(), b.detach().cpu().numpy()) <= 1e-5
+            assert hp.rel_err(a.detach().cpu().numpy(), b.detach().cpu().numpy()) <= 3e-4
     finally:
         dist.destroy_process_group()
 
