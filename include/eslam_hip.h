@@ -121,6 +121,16 @@ int eslam_render_fwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, c
                      float* rgb, float* sdf, float* raw_rgb, float* feat, const int32_t* ray_order,
                      eslam_stream_t stream);
 
+/* eslam_render_fwd that also forms the sums of the callers' mapping loss (src/Mapper.py:110-144,337-346) in its
+ * epilogue, from the depth / rgb / sdf it holds in registers: acc [ESLAM_LOSS_ACC] and loss [1] (may be NULL) exactly as
+ * eslam_loss_value produces them, scratch as there, ray_mask as there (optional).  eslam_loss_grad(acc) then gives the
+ * upstream gradients for eslam_render_bwd.  Not for the tracker's loss: its outlier mask depends on the rendered depth. */
+int eslam_render_fwd_loss(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
+                          const float* rays_o, const float* rays_d, const float* z_vals, int R, int S, float* depth,
+                          float* rgb, float* sdf, float* raw_rgb, float* feat, const int32_t* ray_order,
+                          const float* gt_depth, const float* gt_color, double truncation, const float* weights5_host,
+                          const uint8_t* ray_mask, float* scratch, float* acc, float* loss, eslam_stream_t stream);
+
 /* Mixed-precision forward for inference (BASELINE.json configs[4], a tolerance study): planes_f16[i].data points to
  * IEEE-half data of a channels-last [1,32,h,w] plane (strides in half elements: stride_c = 1, stride_x = 32), the decoder
  * weights are rounded to bf16 inside the kernel and run on bf16 MFMA with float32 accumulation; everything after the MLPs
