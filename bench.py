@@ -289,6 +289,10 @@ def run():
                                    "mapping iteration: sample + render fwd + loss + bwd (planes+decoders), no optimiser",
                        "rays_after_aabb_filter": wl.R, "samples_per_ray": wl.S, "plane_bytes": wl.scene.plane_bytes,
                        "planes_layout": "channels_last", "parallelism": f"ray-sharded dp{world}",
+                       "loss": ("eslam_loss_reduce + all-reduce + eslam_loss_grad" if mapper is not None else
+                                "separate eslam_loss_value launch" if harness._SEPARATE_LOSS else
+                                "sums formed in the forward kernel's epilogue (eslam_render_fwd_loss)") +
+                               "; gradients by eslam_loss_grad in the backward",
                        "launch": ("hipGraph replay of the captured iteration" + (" (2 graphs, all-reduces eager)" if mapper is not None
                                                                                               else ""))
                        if graphed else "eager launches from Python"},
