@@ -151,6 +151,16 @@ class ShardedMapper:
         planes = self.params[:12]
         self._can_mark = bool(self.compact and planes[0].is_cuda and
                               all(p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last) for p in planes))
+        if self.compact and planes[0].is_cuda and dist.is_available() and dist.is_initialized():
+            # one collective probe at construction (every rank builds its mapper): if the backend cannot MAX-reduce bytes,
+            # all ranks fall back to the dense all-reduce together instead of failing in the first iteration
+            try:
+                probe = torch.zeros(8, dtype=torch.uint8, device=workload.device)
+                dist.all_reduce(probe, op=dist.ReduceOp.MAX, group=group)
+            except Exception as e:          # noqa: BLE001 - any backend error means "not supported here"
+                import warnings
+                warnings.warn(f"block-sparse gradient exchange disabled ({type(e).__name__}: {e}); using the dense all-reduce")
+                self.compact = self._can_mark = False
         if self._can_mark:
             self._touched = torch.zeros(self._n_plane_elems // 32, dtype=torch.uint8, device=workload.device)
             self._block_base = (ctypes.c_int64 * 12)(*[self.grads.offsets[i] // 32 for i in range(12)])
