@@ -289,6 +289,9 @@ def run():
                                    "mapping iteration: sample + render fwd + loss + bwd (planes+decoders), no optimiser",
                        "rays_after_aabb_filter": wl.R, "samples_per_ray": wl.S, "plane_bytes": wl.scene.plane_bytes,
                        "planes_layout": "channels_last", "parallelism": f"ray-sharded dp{world}",
+                       "gradient_exchange": None if mapper is None else
+                       ("block-sparse: union of touched texels (ESLAM_DP_COMPACT=0 for dense)" if mapper.compact
+                        else "dense all-reduce of the 27 MB flat buffer"),
                        "loss": ("eslam_loss_reduce + all-reduce + eslam_loss_grad" if mapper is not None else
                                 "separate eslam_loss_value launch" if harness._SEPARATE_LOSS else
                                 "sums formed in the forward kernel's epilogue (eslam_render_fwd_loss)") +
