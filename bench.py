@@ -5,18 +5,27 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one mapping iteration minus the optimiser update: depth-guided sampling ->
-render_batch_ray forward -> mapping loss -> backward to the 12 planes and the decoders, on BASELINE.json configs[1]:
-synthetic Replica room0, 4096 rays x 64 samples (56 stratified + 8 surface), float32, inputs resident in HBM.
-With N > 1 every rank renders its own 4096 rays (weak scaling) and the iteration adds the two collectives of
-myslam_amd/parallel.py (16-float loss denominators, 27 MB gradient all-reduce over RCCL/xGMI).
+render_batch_ray forward -> mapping loss -> backward to the 12 planes and the decoders, float32, inputs resident in HBM.
 
-value = ray.samples/s of the whole job = N * R_eff * S / t_step, t_step = max over ranks of (wall time of K steps)/K.
-roofline = dominant kernel's ALGORITHMIC bytes per launch / its HIP-event-timed duration.
-cpu_baseline = the CPU oracle (a restatement of the reference's PyTorch path, pinned to the reference by
-tests/golden) timed on this box's host cores on the same workload - a reported baseline, not the target.
+  N = 1 (default)   BASELINE.json configs[1]: synthetic Replica room0, 4096 rays x 64 samples (56 stratified + 8 surface).
+  N > 1 (default)   BASELINE.json configs[3], the split north_star names: ONE synthetic ScanNet scene0000 batch of
+                    8192 rays x 96 samples (10 % depth-less rays), identical on every rank, each rank renders its
+                    contiguous 1/N slice (parallel.shard_slice) and the ranks exchange the loss's set sizes + touched
+                    texels (one int32 all-reduce) and the gradients (block-sparse all-reduce) over RCCL / xGMI:
+                    "scaling": "strong".  --strong runs the same workload at N = 1 (the unsharded step through the same
+                    code); --weak gives every rank its own 4096 x 64 room0 batch instead ("scaling": "weak").
+
+value = ray.samples/s of the whole job = (rays of the job) * S / t_step, t_step = max over ranks of (wall time of K steps)/K.
+roofline = per kernel, against the ceiling that actually bounds it (/opt/skills/guides/MI355X_MICROARCH.md): the forward
+gather against the aggregate L2 rate, the scatter against the chip-wide float-atomic rate, the decoder backward against
+HBM and the fp32 MFMA rate; durations are HIP events on the launch stream, bytes the rocprofv3 PMC counters of THIS build
+(profiles/r02_traffic.json, keyed by the library's hash - stale numbers are dropped, not shown).
+cpu_baseline = the CPU oracle (a restatement of the reference's PyTorch path, pinned to the reference by tests/golden)
+timed on this box's host cores on the same workload - a reported baseline, not the target.
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import sys
@@ -27,11 +36,21 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SCENE, RAYS, N_STRAT, N_IMP = "room0", 4096, 56, 8
-HBM_PEAK_GBS = 8000.0                 # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
-# algorithmic bytes per ray.sample: 12 planes x 4 texels x 32 ch x 4 B gathered (fwd),
-# the same footprint scatter-added (bwd), + 16 B of per-sample I/O
-BYTES_FWD, BYTES_SCATTER = 6160, 6144
+SINGLE = dict(scene="room0", rays=4096, n_strat=56, n_imp=8, zero_frac=0.0,
+              name="BASELINE configs[1]: Replica room0 (synthetic), 4096 rays x 64 samples (56+8)")
+STRONG = dict(scene="scene0000", rays=8192, n_strat=88, n_imp=8, zero_frac=0.1,
+              name="BASELINE configs[3]: ScanNet scene0000 (synthetic), ONE batch of 8192 rays x 96 samples (88+8), 10 % "
+                   "depth-less rays, ray-sharded")
+# ceilings, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0             # HBM3E spec (6.3 TB/s achievable by a streaming copy)
+L2_PEAK_GBS = 34500.0             # aggregate L2 -> L1 rate ("L2 (per XCD)": ~34.5 TB/s)
+L2_GATHER_MEASURED_GBS = (16800.0, 18800.0)    # guide's measured rate of an L2-resident row gather into LDS
+ATOMIC_PEAK_GBS = 1300.0          # chip-wide global float atomics, added bytes
+MFMA_F32_PEAK_TFLOPS = 157.3      # fp32-input MFMA = fp32 vector rate
+# algorithmic work per ray.sample: 12 planes x 4 texels x 32 ch x 4 B gathered (+16 B of sample
+# I/O); the same footprint scatter-added; decoder GEMMs 2624 MAC forward, x3 in the backward (recompute + dX + dW)
+BYTES_FWD, BYTES_SCATTER, BYTES_STEP = 6160, 6144, 12304
+FLOP_MLP_BWD = 3 * 2 * 2624
 
 
 def parse():
@@ -42,27 +61,47 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-iters", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true", help="issue every launch eagerly from Python (no hipGraph)")
+    ap.add_argument("--weak", action="store_true", help="N > 1: every rank renders its own 4096 x 64 room0 batch")
+    ap.add_argument("--strong", action="store_true", help="N = 1: run the configs[3] workload of the N > 1 mode unsharded")
+    ap.add_argument("--no-extras", action="store_true", help="skip eager / NCHW / forward-only side measurements")
     return ap.parse_args()
+
+
+def lib_hash():
+    from myslam_amd import _hip
+    return hashlib.sha256(open(_hip.LIB_PATH, "rb").read()).hexdigest()[:16]
 
 
 def kernel_profile(step_fn, iters):
     """Average HIP-event duration (ms) of every kernel of one step; events sit on the launch stream in the C-ABI."""
     from myslam_amd import _hip
     lib = _hip.lib()
+    nk = _hip.PROF_KERNELS
     sums, cnt = {}, {}
-    buf = (ctypes.c_float * 12)()
+    buf = (ctypes.c_float * nk)()
     for _ in range(iters):
         _hip.check(lib.eslam_profile_enable(1), "profile_enable")
         step_fn()
         torch.cuda.synchronize()
         _hip.check(lib.eslam_profile_read(buf), "profile_read")
-        for i in range(12):
+        for i in range(nk):
             if buf[i] >= 0:
                 n = lib.eslam_profile_name(i).decode()
                 sums[n] = sums.get(n, 0.0) + buf[i]
                 cnt[n] = cnt.get(n, 0) + 1
     lib.eslam_profile_enable(0)
     return {k: sums[k] / cnt[k] for k in sums}
+
+
+def timed(fn, n, warm):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
 
 
 def cpu_baseline(wl, budget_s=25.0, max_iters=5):
@@ -150,11 +189,10 @@ def main():
         print(line, flush=True)
 
 
-def step_statistics(step, wl, n=100):
-    """SURVEY.md section 8(d) asks for median and p10 / p90 and for the forward-only rate beside the headline number.
-    Each step is bracketed by its own pair of events here (that adds a little launch gap per step, so the median sits a
-    few microseconds above ms_per_step, which times K steps back to back)."""
-    from myslam_amd import harness
+def step_statistics(step, n=100):
+    """SURVEY.md section 8(d) asks for median and p10 / p90 beside the headline number.  Each step is bracketed by its own
+    pair of events here (that adds a little launch gap per step, so the median sits a few microseconds above
+    ms_per_step, which times K steps back to back)."""
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
     for a, b in ev:
         a.record()
@@ -162,28 +200,105 @@ def step_statistics(step, wl, n=100):
         b.record()
     torch.cuda.synchronize()
     ts = sorted(a.elapsed_time(b) for a, b in ev)
-    pct = {"p10": round(ts[n // 10], 4), "p50": round(ts[n // 2], 4), "p90": round(ts[(9 * n) // 10], 4), "n": n}
+    return {"p10": round(ts[n // 10], 4), "p50": round(ts[n // 2], 4), "p90": round(ts[(9 * n) // 10], 4), "n": n}
 
-    def fwd():
-        with torch.no_grad():
-            wl.renderer.render_batch_ray(wl.planes, wl.decoders, wl.rays_d, wl.rays_o, wl.device, wl.truncation,
-                                         gt_depth=wl.gt_depth)
-    fwd_only = None
+
+def side_measurements(cfg, wl, dev):
+    """What the same iteration costs a caller that does NOT replay a graph, or keeps the reference's NCHW planes
+    (src/ESLAM.py:201-210) - VERDICT r01 weak #5 - and the forward-only rate SURVEY.md section 8(d) asks for."""
+    from myslam_amd import harness, losses
+    out = {}
     try:
+        out["eager_ms_per_step"] = round(timed(wl.step, 50, 10), 4)       # same step, every launch issued from Python
+
+        def reference_shaped():      # the reference loop's own call sequence: render_batch_ray, then the loss, then backward
+            for p in wl.params():
+                p.grad = None
+            d, c, s, z = wl.renderer.render_batch_ray(wl.planes, wl.decoders, wl.rays_d, wl.rays_o, wl.device, wl.truncation,
+                                                      gt_depth=wl.gt_depth)
+            losses.mapping_loss(d, c, s, z, wl.gt_depth, wl.gt_color, wl.truncation).backward()
+        out["eager_separate_loss_ms_per_step"] = round(timed(reference_shaped, 50, 10), 4)
+        wn = harness.make_workload(cfg["scene"], cfg["rays"], cfg["n_strat"], cfg["n_imp"], device=dev,
+                                   zero_frac=cfg["zero_frac"], channels_last=False)
+        gn = harness.GraphedStep(wn.step, wn.params())
+        out["nchw_ms_per_step"] = round(timed(gn, 50, 10), 4)            # reference-layout planes, graph replay
+        out["nchw_eager_ms_per_step"] = round(timed(wn.step, 20, 5), 4)
+        del gn, wn
+
+        def fwd():
+            with torch.no_grad():
+                wl.renderer.render_batch_ray(wl.planes, wl.decoders, wl.rays_d, wl.rays_o, wl.device, wl.truncation,
+                                             gt_depth=wl.gt_depth)
         g = harness.GraphedStep(fwd, [])
-        for _ in range(10):
-            g()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            g()
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / n * 1e3
-        fwd_only = {"ms": round(ms, 4), "value": wl.R * wl.S / (ms * 1e-3), "unit": "ray.samples/s",
-                    "what": "sample + render_batch_ray forward only (no_grad: nothing saved for backward), graph replay"}
-    except Exception as e:
-        fwd_only = {"error": f"{type(e).__name__}: {e}"}
-    return {"percentiles": pct, "forward_only": fwd_only}
+        ms = timed(g, 100, 10)
+        out["forward_only"] = {"ms": round(ms, 4), "value": wl.R * wl.S / (ms * 1e-3), "unit": "ray.samples/s",
+                               "what": "sample + render_batch_ray forward only (no_grad: nothing saved for backward), graph replay"}
+    except Exception as e:       # report, never hide
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
+def roofline(prof, n, ms_step):
+    """Per-kernel roofline entries + the contract's `roofline` object (the kernel with the longest duration)."""
+    traffic = {}
+    traffic_note = "no PMC file for this build (profiles/r02_traffic.json missing or from another library hash): traffic = null"
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+        if tj.get("lib_sha256_16") == lib_hash() and tj.get("ray_samples") == n:
+            traffic = tj["kernels"]
+            traffic_note = "profiles/r02_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC passes of this library build on this workload"
+    except Exception:
+        pass
+
+    def entry(kernel, bound, alg_bytes, peak, unit="GB/s", extra=None):
+        if kernel not in prof:
+            return None
+        t = prof[kernel] * 1e-3
+        tr = traffic.get(kernel, {})
+        e = {"kernel": kernel, "bound": bound, "avg_kernel_ms": round(prof[kernel], 5), "peak": peak, "unit": unit,
+             "algorithmic_bytes_per_launch": alg_bytes, "traffic": tr.get("traffic_bytes")}
+        if bound == "l2":            # every algorithmic byte is a 16-B-per-lane request served by L1/L2
+            e["achieved"] = alg_bytes / t / 1e9
+            e["peak_note"] = (f"aggregate L2 rate; the guide's MEASURED rate of an L2-resident row gather is "
+                              f"{L2_GATHER_MEASURED_GBS[0] / 1e3:.1f}-{L2_GATHER_MEASURED_GBS[1] / 1e3:.1f} TB/s")
+        elif bound == "atomic":      # what the memory side adds: WRITE_SIZE of the atomics (exact for float atomics)
+            ab = tr.get("atomic_bytes")
+            e["achieved"] = None if ab is None else ab / t / 1e9
+            e["algorithmic_rate_GBs"] = alg_bytes / t / 1e9
+        elif bound == "hbm":
+            tb = tr.get("traffic_bytes")
+            e["achieved"] = None if tb is None else tb / t / 1e9
+        e["frac"] = None if e.get("achieved") is None else e["achieved"] / peak
+        if extra:
+            e.update(extra)
+        return e
+
+    ks = [entry("render_fwd_kernel", "l2", BYTES_FWD * n, L2_PEAK_GBS),
+          entry("scatter_sort_kernel", "atomic", BYTES_SCATTER * n, ATOMIC_PEAK_GBS),
+          entry("mlp_bwd_kernel", "hbm", 2 * 512 * n, HBM_PEAK_GBS,
+                extra={"mfma": {"flops_per_launch": FLOP_MLP_BWD * n, "peak_tflops": MFMA_F32_PEAK_TFLOPS,
+                                "achieved_tflops": None if "mlp_bwd_kernel" not in prof else
+                                FLOP_MLP_BWD * n / (prof["mlp_bwd_kernel"] * 1e-3) / 1e12,
+                                "note": "useful flops (2624 MAC x 3); the 16x16x4 tiles are zero-padded on the 1- and 3-wide output layers"}})]
+    ks = [k for k in ks if k]
+    step_traffic = sum(v.get("traffic_bytes", 0) for v in traffic.values()) if traffic else None
+    whole = {"bound": "hbm", "traffic": step_traffic, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "achieved": None if step_traffic is None else step_traffic / (ms_step * 1e-3) / 1e9,
+             "algorithmic_bytes": BYTES_STEP * n, "algorithmic_rate_GBs": BYTES_STEP * n / (ms_step * 1e-3) / 1e9,
+             "note": "memory-side bytes of all kernels of a step (PMC) / ms_per_step; the algorithmic figure of SURVEY.md 8(d) "
+                     "is kept as a labelled extra: the planes are L2 / Infinity-Cache resident, so it is NOT an HBM rate"}
+    whole["frac"] = None if whole["achieved"] is None else whole["achieved"] / HBM_PEAK_GBS
+    dom = max(ks, key=lambda e: e["avg_kernel_ms"]) if ks else None
+    top = None
+    if dom is not None:
+        top = {k: dom.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_kernel_ms",
+                                       "algorithmic_bytes_per_launch")}
+        if top["achieved"] is None:          # no PMC numbers for this build: fall back to the rate the events alone give
+            top["note"] = "achieved needs the PMC bytes of this build; see kernels[] for the event-timed algorithmic rates"
+        top["traffic_source"] = traffic_note
+        top["kernels"] = ks
+        top["whole_step"] = whole
+    return top
 
 
 def run():
@@ -206,9 +321,16 @@ def run():
         dist.init_process_group("nccl", device_id=dev)
 
     from myslam_amd import harness
-    wl = harness.make_workload(SCENE, RAYS, N_STRAT, N_IMP, device=dev, seed=rank)
+    strong = (world > 1 and not args.weak) or (world == 1 and args.strong)
+    cfg = STRONG if strong else SINGLE
+    if strong:       # ONE batch, the same on every rank; this rank keeps its contiguous slice
+        wl = harness.make_workload(cfg["scene"], cfg["rays"], cfg["n_strat"], cfg["n_imp"], device=dev,
+                                   zero_frac=cfg["zero_frac"], seed=0, shard=(rank, world))
+    else:
+        wl = harness.make_workload(cfg["scene"], cfg["rays"], cfg["n_strat"], cfg["n_imp"], device=dev,
+                                   zero_frac=cfg["zero_frac"], seed=rank)
     mapper = None
-    if world > 1 or os.environ.get("BENCH_FORCE_DP") == "1":      # BENCH_FORCE_DP: exercise the sharded step on one rank
+    if world > 1 or strong or os.environ.get("BENCH_FORCE_DP") == "1":   # BENCH_FORCE_DP: the sharded step on one rank
         from myslam_amd.parallel import ShardedMapper
         if world == 1:
             import torch.distributed as dist
@@ -222,8 +344,8 @@ def run():
     eager_step = step
     graphed = False
     if not args.no_graph:
-        # capture the iteration into hipGraphs: the step is launch-bound when issued from Python.  With N > 1 the two
-        # collective-free phases of the sharded step are captured separately and the two RCCL all-reduces stay eager.
+        # capture the iteration into hipGraphs: the step is launch-bound when issued from Python.  With a mapper the
+        # collective-free phases of the sharded step are captured separately and the two all-reduces stay eager.
         try:
             if mapper is not None:
                 mapper.capture()
@@ -261,64 +383,59 @@ def run():
     value = total_rays * wl.S / (dt / args.steps)
 
     out = None
-    extras = None
-    if rank == 0 and world == 1:
-        extras = step_statistics(step, wl)       # outside the timed region: per-step percentiles, forward-only rate
+    prof = None
+    if mapper is not None:           # the sharded step contains collectives: every rank takes part in the profiled steps
+        prof = kernel_profile(mapper._eager, max(3, args.profile_iters // 4))
     if rank == 0:
-        prof = kernel_profile(wl.step, args.profile_iters)      # eager: the HIP events sit inside the C-ABI calls
+        pct = step_statistics(step) if world == 1 else None        # outside the timed region
+        if prof is None:
+            prof = kernel_profile(wl.step, args.profile_iters)      # eager: the HIP events sit inside the C-ABI calls
         n = wl.R * wl.S
-        alg = {"render_fwd_kernel": BYTES_FWD * n, "scatter_sort_kernel": BYTES_SCATTER * n}
-        dom = max((k for k in prof if k in alg), key=lambda k: prof[k])
-        achieved = alg[dom] / (prof[dom] * 1e-3) / 1e9
-        other = [k for k in alg if k != dom][0]
-        # HBM-side traffic per launch comes from the separate rocprofv3 --pmc passes of this build (profiles/): counters
-        # cannot be read from inside this process
-        traffic, traffic_note = None, None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if dom in tj and wl.R * wl.S == 4096 * 64:
-                traffic = tj[dom]["traffic_bytes"]
-                traffic_note = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload)"
-        except Exception:
-            pass
         out = {
             "metric": "ray.samples/s (render+bwd)", "value": value, "unit": "ray.samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"Replica room0 (synthetic), {RAYS} rays x {wl.S} samples ({N_STRAT}+{N_IMP}) per GPU, "
-                                   "mapping iteration: sample + render fwd + loss + bwd (planes+decoders), no optimiser",
-                       "rays_after_aabb_filter": wl.R, "samples_per_ray": wl.S, "plane_bytes": wl.scene.plane_bytes,
-                       "planes_layout": "channels_last", "parallelism": f"ray-sharded dp{world}",
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg["name"] + "; mapping iteration: sample + render fwd + loss + bwd (planes+decoders), "
+                                   "no optimiser",
+                       "rays_of_the_job": total_rays, "rays_this_rank": wl.R, "samples_per_ray": wl.S,
+                       "plane_bytes": wl.scene.plane_bytes, "planes_layout": "channels_last",
+                       "parallelism": f"ray-sharded dp{world}" if mapper is not None else "single GPU",
                        "gradient_exchange": None if mapper is None else
                        ("block-sparse: union of touched texels (ESLAM_DP_COMPACT=0 for dense)" if mapper.compact
-                        else "dense all-reduce of the 27 MB flat buffer"),
-                       "loss": ("eslam_loss_reduce + all-reduce + eslam_loss_grad" if mapper is not None else
-                                "separate eslam_loss_value launch" if harness._SEPARATE_LOSS else
-                                "sums formed in the forward kernel's epilogue (eslam_render_fwd_loss)") +
-                               "; gradients by eslam_loss_grad in the backward",
-                       "launch": ("hipGraph replay of the captured iteration" + (" (2 graphs, all-reduces eager)" if mapper is not None
+                        else "dense all-reduce of the flat gradient buffer"),
+                       "collectives_per_step": None if mapper is None else 2,
+                       "loss": "sums formed in the forward kernel's epilogue (eslam_render_fwd_loss), gradients formed inside "
+                               "the backward kernel (eslam_render_bwd_loss)" +
+                               ("; set sizes made global by the int32 sync all-reduce" if mapper is not None else ""),
+                       "launch": ("hipGraph replay of the captured iteration" + (" (2 graphs, collectives eager)" if mapper is not None
                                                                                               else ""))
                        if graphed else "eager launches from Python"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
-                         "note": "the 27 MB of planes are L2 / Infinity-Cache resident and duplicate texel contributions are "
-                                 "merged on chip before they reach memory, so algorithmic bytes per second can exceed the HBM "
-                                 "peak; traffic is what the memory side actually saw",
-                         "algorithmic_bytes_per_launch": alg[dom], "avg_kernel_ms": prof[dom],
-                         "second_kernel": {"kernel": other, "avg_kernel_ms": prof.get(other),
-                                           "achieved": alg[other] / (prof[other] * 1e-3) / 1e9 if other in prof else None},
-                         "whole_step": {"algorithmic_bytes": 12304 * n, "achieved": 12304 * n / (ms_step * 1e-3) / 1e9,
-                                        "frac": 12304 * n / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+            "roofline": roofline(prof, n, ms_step) if mapper is None else None,
             "kernel_ms": {k: round(v, 4) for k, v in sorted(prof.items())},
-            "step_ms_percentiles": None if extras is None else extras["percentiles"],
-            "forward_only": None if extras is None else extras["forward_only"],
+            "step_ms_percentiles": pct,
         }
+        if mapper is None and not args.no_extras:
+            out.update(side_measurements(cfg, wl, dev))
+        if strong and not args.no_extras:
+            # the SAME batch unsharded on this one GPU, through the single-GPU step: what a strong-scaling speed-up is against
+            try:
+                wf = harness.make_workload(cfg["scene"], cfg["rays"], cfg["n_strat"], cfg["n_imp"], device=dev,
+                                           zero_frac=cfg["zero_frac"], seed=0)
+                gf = harness.GraphedStep(wf.step, wf.params())
+                ms1 = timed(gf, 50, 10)
+                out["single_gpu_same_workload"] = {"ms_per_step": round(ms1, 4), "value": wf.R * wf.S / (ms1 * 1e-3),
+                                                   "unit": "ray.samples/s", "rays": wf.R,
+                                                   "what": "the whole batch on rank 0's GPU, single-GPU graph replay, measured "
+                                                           "in this job after the timed region"}
+                del gf, wf
+            except Exception as e:
+                out["single_gpu_same_workload"] = {"error": f"{type(e).__name__}: {e}"}
     if world > 1:
         dist.barrier()
     line = None
     if rank == 0:
         # reported on rank 0 at N=1 only (a host-side baseline does not change with the GPU count)
-        out["cpu_baseline"] = cpu_baseline(wl) if (world == 1 and not args.no_cpu_baseline) else None
+        out["cpu_baseline"] = cpu_baseline(wl) if (world == 1 and not strong and not args.no_cpu_baseline) else None
         if out["cpu_baseline"] is not None:
             # same baseline leg, second device: the port's PyTorch ops run on this GPU instead of the host cores
             try:

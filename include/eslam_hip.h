@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ESLAM_ABI_VERSION 1
+#define ESLAM_ABI_VERSION 2
 #define ESLAM_C_DIM 32          /* feature channels per plane (configs/ESLAM.yaml:77)               */
 #define ESLAM_HIDDEN 16         /* decoder hidden width (src/networks/decoders.py:39)               */
 #define ESLAM_FEAT (2 * ESLAM_C_DIM)   /* coarse || fine                                          */
@@ -107,6 +107,17 @@ int eslam_sample_z_all(const eslam_plane_t* planes, const eslam_decoders_t* dec,
                        double truncation, const float* t_free, const float* t_surf, const float* t_rand,
                        const float* t_rand_uni, const float* u, float* z_vals, eslam_stream_t stream);
 
+/* eslam_sample_z_all with the random numbers drawn INSIDE the kernel instead of read from t_rand / t_rand_uni / u (the
+ * reference draws them with torch.rand, Renderer.py:59 and common.py:59; a caller that needs the reference's exact
+ * stream injects it through eslam_sample_z_all): U = hash(seed, step, stream, element) / 2^24 in [0,1), with
+ * step = *rng_state (device memory; NULL = 0).  perturb = 0 leaves the samples un-jittered (Renderer.perturb False);
+ * the importance draw is random either way.  Pass the same rng_state as `rng_bump` to the eslam_render_fwd* call that
+ * consumes z_vals: it advances the step, so a replayed hipGraph draws fresh numbers without an extra launch.        */
+int eslam_sample_z_all_rng(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
+                           const float* rays_o, const float* rays_d, const float* gt_depth, int R, int n_strat, int n_imp,
+                           double truncation, const float* t_free, const float* t_surf, int perturb, uint64_t seed,
+                           const uint32_t* rng_state, float* z_vals, eslam_stream_t stream);
+
 /* K5-K7 forward.  Replaces src/utils/Renderer.py:136-147 + src/networks/decoders.py:64-146 +
  * src/common.py:204-218:  pts = o + d z -> normalise -> tri-plane bilinear gather (border, align_corners) ->
  * SDF / colour MLPs -> sdf2alpha -> transmittance scan -> composite.
@@ -115,11 +126,12 @@ int eslam_sample_z_all(const eslam_plane_t* planes, const eslam_decoders_t* dec,
  * ray_order [R] (optional, from eslam_ray_order): the kernel walks the rays in that order with an XCD-contiguous
  * block mapping; outputs stay in the caller's ray order.  NULL = rays are processed as given, which measured FASTER
  * on MI355X (119 vs 123-125 us at 4096 x 64: neighbouring rays in flight together hit the same L2 channels), so the
- * shipped binding passes NULL here and hands the order to eslam_render_bwd only, whose scatter needs it.        */
+ * shipped binding passes NULL here and hands the order to eslam_render_bwd only, whose scatter needs it.
+ * rng_bump (optional): a device counter this launch increments by one (see eslam_sample_z_all_rng).            */
 int eslam_render_fwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
                      const float* rays_o, const float* rays_d, const float* z_vals, int R, int S, float* depth,
                      float* rgb, float* sdf, float* raw_rgb, float* feat, const int32_t* ray_order,
-                     eslam_stream_t stream);
+                     uint32_t* rng_bump, eslam_stream_t stream);
 
 /* eslam_render_fwd that also forms the sums of the callers' mapping loss (src/Mapper.py:110-144,337-346) in its
  * epilogue, from the depth / rgb / sdf it holds in registers: acc [ESLAM_LOSS_ACC] and loss [1] (may be NULL) exactly as
@@ -129,7 +141,8 @@ int eslam_render_fwd_loss(const eslam_plane_t* planes, const eslam_decoders_t* d
                           const float* rays_o, const float* rays_d, const float* z_vals, int R, int S, float* depth,
                           float* rgb, float* sdf, float* raw_rgb, float* feat, const int32_t* ray_order,
                           const float* gt_depth, const float* gt_color, double truncation, const float* weights5_host,
-                          const uint8_t* ray_mask, float* scratch, float* acc, float* loss, eslam_stream_t stream);
+                          const uint8_t* ray_mask, float* scratch, float* acc, float* loss, uint32_t* rng_bump,
+                          eslam_stream_t stream);
 
 /* Mixed-precision forward for inference (BASELINE.json configs[4], a tolerance study): planes_f16[i].data points to
  * IEEE-half data of a channels-last [1,32,h,w] plane (strides in half elements: stride_c = 1, stride_x = 32), the decoder
@@ -160,6 +173,23 @@ int eslam_render_bwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, c
                      const float* sdf, const float* raw_rgb, const float* feat, const float* g_depth,
                      const float* g_rgb, const float* g_sdf, float* g_dec, float* g_beta, float* g_rays_o,
                      float* g_rays_d, const int32_t* ray_order, void* workspace, eslam_stream_t stream);
+
+/* eslam_render_bwd for an iteration whose loss is the mapping loss (src/Mapper.py:110-144,337-346; with ray_mask the
+ * tracker's, src/Tracker.py:114-148,197-204): the upstream gradients d loss / d (depth, rgb, sdf) are formed INSIDE the
+ * backward kernel from acc [ESLAM_LOSS_ACC] - the set sizes and sums eslam_render_fwd_loss / eslam_loss_value /
+ * eslam_loss_reduce (+ all-reduce) produced - instead of being written by eslam_loss_grad and read back: loss gradient,
+ * composite backward and decoder backward are one launch.  depth [R], rgb [R,3]: the forward outputs.  upstream [1] on
+ * the device = d L / d loss (NULL = 1).  loss_out [1] (optional): receives the loss value formed from acc (a ray-sharded
+ * caller's acc is only complete after its all-reduce).  g_depth / g_rgb / g_sdf (each optional): FURTHER upstream
+ * gradients on the rendered outputs, added to the loss's own.  Everything else as eslam_render_bwd.                */
+int eslam_render_bwd_loss(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
+                          const float* rays_o, const float* rays_d, const float* z_vals, int R, int S,
+                          const float* sdf, const float* raw_rgb, const float* feat, const float* depth,
+                          const float* rgb, const float* gt_depth, const float* gt_color, double truncation,
+                          const float* weights5_host, const uint8_t* ray_mask, const float* acc,
+                          const float* upstream, float* loss_out, const float* g_depth, const float* g_rgb,
+                          const float* g_sdf, float* g_dec, float* g_beta, float* g_rays_o, float* g_rays_d,
+                          const int32_t* ray_order, void* workspace, eslam_stream_t stream);
 
 /* Decoder-only query.  Replaces src/networks/decoders.py:127-146 (Decoders.forward), the entry used by
  * src/utils/Mesher.py:151 on up to 500k points.  pts [N,3] world coordinates -> raw [N,4] = (r,g,b,sdf).
@@ -304,6 +334,18 @@ int eslam_blocks_unpack(float* flat, const int64_t* idx, int64_t n_idx, float* t
 int eslam_profile_enable(int on);
 int eslam_profile_read(float* ms_out);
 const char* eslam_profile_name(int kernel_id);
+
+/* The one collective between the forward and the backward pass of a ray-sharded mapping iteration (new: the reference is
+ * single-GPU).  eslam_shard_sync_pack writes this rank's five loss set sizes (from acc
+ * [ESLAM_LOSS_ACC], src/Mapper.py:136-140,343,346 take means over them) and its touched-texel bytes (eslam_mark_touched;
+ * n_blocks may be 0) into out [eslam_shard_sync_words(n_blocks)] int32, six texels per word as 4-bit counts; the caller
+ * all-reduces that buffer with SUM (exact in integers, any backend, world <= 15); eslam_shard_sync_unpack then writes
+ * acc_global [ESLAM_LOSS_ACC] = acc_local with the five set sizes replaced by the global ones (what
+ * eslam_render_bwd_loss scales its gradients with) and touched [n_blocks] = the union over ranks.             */
+int64_t eslam_shard_sync_words(int64_t n_blocks);
+int eslam_shard_sync_pack(const float* acc, const uint8_t* touched, int64_t n_blocks, int32_t* out, eslam_stream_t stream);
+int eslam_shard_sync_unpack(const int32_t* in, int64_t n_blocks, const float* acc_local, float* acc_global,
+                            uint8_t* touched, eslam_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -11,8 +11,10 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libeslam_hip.so")
+# ESLAM_HIP_LIB: another build of the SAME library (A/B of compile-time kernel variants, tools/ab_variants.py); never a fallback
+LIB_PATH = os.environ.get("ESLAM_HIP_LIB") or os.path.join(_HERE, "lib", "libeslam_hip.so")
 
+ABI_VERSION = 2              # ESLAM_ABI_VERSION
 N_DEC_PARAMS = 2692
 N_PLANES = 12
 
@@ -46,14 +48,17 @@ SIGNATURES = {
     "eslam_sample_z": (_i, [_vp, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp]),
     "eslam_importance_z": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "eslam_sample_z_all": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "eslam_render_fwd": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "eslam_sample_z_all_rng": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _i, _d, _vp, _vp, _i, ctypes.c_uint64, _vp, _vp, _vp]),
+    "eslam_render_fwd": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "eslam_render_fwd_loss": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _BP, _vp,
-                                   _vp, _vp, _vp, _vp]),
+                                   _vp, _vp, _vp, _vp, _vp]),
     "eslam_render_fwd_lowp": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "eslam_ray_order": (_i, [_vp, _vp, _i, _vp, _vp]),
     "eslam_bwd_workspace_bytes": (_i64, [_i64]),
     "eslam_render_bwd": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                               _vp, _vp, _vp]),
+    "eslam_render_bwd_loss": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _BP, _vp, _vp,
+                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "eslam_decode_fwd": (_i, [_PP, _DP, _BP, _vp, _i64, _i, _vp, _vp, _vp]),
     "eslam_decode_bwd": (_i, [_PP, _DP, _BP, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "eslam_mapping_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _BP, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -73,6 +78,9 @@ SIGNATURES = {
     "eslam_blocks_touched": (_i, [_vp, _i64, _vp, _vp]),
     "eslam_blocks_pack": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "eslam_blocks_unpack": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "eslam_shard_sync_words": (_i64, [_i64]),
+    "eslam_shard_sync_pack": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "eslam_shard_sync_unpack": (_i, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "eslam_keyframe_overlap": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _f, _f, _f, _f, _i, _vp, _vp]),
 }
 
@@ -104,8 +112,8 @@ def load_library(path=None):
             fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
             fn.restype = res
             fn.argtypes = args
-        if lib.eslam_abi_version() != 1:
-            raise RuntimeError(f"ABI mismatch: library reports version {lib.eslam_abi_version()}, binding expects 1")
+        if lib.eslam_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"ABI mismatch: library reports version {lib.eslam_abi_version()}, binding expects {ABI_VERSION}")
         if path is None:
             _lib = lib
         return lib

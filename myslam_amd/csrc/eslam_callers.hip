@@ -235,3 +235,77 @@ extern "C" int eslam_blocks_unpack(float* flat, const int64_t* idx, int64_t n_id
                                    const float* buf, eslam_stream_t stream) {
     return blocks_move(false, flat, idx, n_idx, tail, n_tail, (float*)buf, stream);
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// ONE collective between the forward and the backward pass of a ray-sharded mapping iteration (myslam_amd/parallel.py):
+// the five set sizes of the loss (src/Mapper.py:136-140,343,346 take means over them) and the union of texels the ranks'
+// backward passes will touch travel in one int32 buffer that is all-reduced with SUM - exact, order-independent, and
+// supported by every backend (round 1 needed a 16-float SUM and a byte MAX, two latency-bound collectives).
+//   word 0..4   N_front, N_center, N_tail, N_depth, N_color of this rank's rays (integers; the loss SUMS are not needed
+//               before the backward pass and ride in the gradient exchange instead)
+//   word 8 + k  six texels per word, 4 bits each: (touched[6k+i] != 0) << 4i.  After the SUM a nibble holds the number of
+//               ranks that touch the texel (world <= 15, no carry into the next nibble).
+// ---------------------------------------------------------------------------------------------------------
+#include "eslam_loss_final.h"
+#define SYNC_HEAD 8
+
+__global__ __launch_bounds__(256) void shard_sync_pack_kernel(const float* __restrict__ acc, const uint8_t* __restrict__ touched,
+                                                              int64_t n, int32_t* __restrict__ out) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w == 0) {
+        out[0] = (int32_t)acc[A_N_FRONT]; out[1] = (int32_t)acc[A_N_CENTER]; out[2] = (int32_t)acc[A_N_TAIL];
+        out[3] = (int32_t)acc[A_N_DEPTH]; out[4] = (int32_t)acc[A_N_COLOR]; out[5] = out[6] = out[7] = 0;
+    }
+    if (w * 6 >= n) return;
+    int32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        if (w * 6 + i < n && touched[w * 6 + i]) v |= 1 << (4 * i);
+    out[SYNC_HEAD + w] = v;
+}
+
+__global__ __launch_bounds__(256) void shard_sync_unpack_kernel(const int32_t* __restrict__ in, int64_t n,
+                                                                const float* __restrict__ acc_local,
+                                                                float* __restrict__ acc_global, uint8_t* __restrict__ touched) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < ESLAM_LOSS_ACC) {
+        float v = acc_local[w];
+        if (w == A_N_FRONT) v = (float)in[0];
+        else if (w == A_N_CENTER) v = (float)in[1];
+        else if (w == A_N_TAIL) v = (float)in[2];
+        else if (w == A_N_DEPTH) v = (float)in[3];
+        else if (w == A_N_COLOR) v = (float)in[4];
+        acc_global[w] = v;
+    }
+    if (w * 6 >= n) return;
+    const int32_t v = in[SYNC_HEAD + w];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        if (w * 6 + i < n) touched[w * 6 + i] = ((v >> (4 * i)) & 15) ? 1 : 0;
+}
+
+extern "C" int64_t eslam_shard_sync_words(int64_t n_blocks) { return n_blocks < 0 ? -1 : SYNC_HEAD + (n_blocks + 5) / 6; }
+
+extern "C" int eslam_shard_sync_pack(const float* acc, const uint8_t* touched, int64_t n_blocks, int32_t* out,
+                                     eslam_stream_t stream) {
+    if (!acc || !out || n_blocks < 0 || (n_blocks > 0 && !touched)) {
+        eslam_set_error("eslam_shard_sync_pack: null argument");
+        return 1;
+    }
+    const int64_t words = (n_blocks + 5) / 6;
+    hipLaunchKernelGGL(shard_sync_pack_kernel, dim3((unsigned)((words > 0 ? words : 1) + 255) / 256), dim3(256), 0,
+                       (hipStream_t)stream, acc, touched, n_blocks, out);
+    return eslam_check_launch("shard_sync_pack_kernel");
+}
+
+extern "C" int eslam_shard_sync_unpack(const int32_t* in, int64_t n_blocks, const float* acc_local, float* acc_global,
+                                       uint8_t* touched, eslam_stream_t stream) {
+    if (!in || !acc_local || !acc_global || n_blocks < 0 || (n_blocks > 0 && !touched)) {
+        eslam_set_error("eslam_shard_sync_unpack: null argument");
+        return 1;
+    }
+    const int64_t words = (n_blocks + 5) / 6;
+    hipLaunchKernelGGL(shard_sync_unpack_kernel, dim3((unsigned)((words > 16 ? words : 16) + 255) / 256), dim3(256), 0,
+                       (hipStream_t)stream, in, n_blocks, acc_local, acc_global, touched);
+    return eslam_check_launch("shard_sync_unpack_kernel");
+}

@@ -1,18 +1,24 @@
 // Tri-plane gather + fused decoder MLPs for one wave-tile of 64 points (forward direction).
 //
-// Lane roles inside a wave (lane l = 0..63):
+// Lane roles inside a wave (lane l = 0..63); the tile is cut into 4 blocks of 16 points:
 //   "sample role":  lane l owns point l of the tile (per-point scalars: z, sdf, alpha, ...).
-//   "block role":   the tile is cut into 4 blocks of 16 points; for block b lane l works on point 16b + (l & 15)
-//                   and on the channel octet q = l >> 4 (channels 8q..8q+7 of each 32-channel texel).
+//   "gather role":  for block b lane l works on point 16b + (l >> 2) and on piece g = l & 3 of every 32-channel texel:
+//                   channels 4g..4g+3 and 16+4g..16+4g+3 (two 16-byte loads per bilinear corner).
+//   "MFMA role":    lane l = 16 q + r holds column r (= point 16b + r) and k-slot q of the B operand.
 //
-// Gather (block role): per plane and bilinear corner a lane loads its 8 channels as two 16-byte loads, the four
-// q-lanes of a point together cover the texel's 128 contiguous bytes (channels-last planes), so every wave
-// instruction moves 16 full 128-B lines.  The weighted sum stays in registers: feat[level][8].
+// Gather role: the four lanes of a point are CONSECUTIVE lanes, so every quad of lanes reads 64 contiguous bytes of
+// one 128-B texel line.  The texture addresser serves a 16-B-per-lane load one quad per cycle and looks up the lines a
+// quad touches one after the other: with the four lanes of a quad on four different POINTS (the MFMA role's own layout,
+// which round 1 gathered in) the same loads ran 1.8x slower - 112 vs 63 us for the bench workload's 12.6 M texel reads
+// (tools/ubench_gather.hip, profiles/r02/).  The 16 gathered values of a lane then move to the MFMA role with one
+// ds_bpermute_b32 each (a lane rotation l = 4p + g -> 16g + p: no LDS memory, 2 LDS-pipe cycles per register).
+// Planes in the reference's NCHW layout have no texel lines: there consecutive lanes stay on consecutive points (one
+// channel plane per load) and gather role = MFMA role.
 //
 // MLP (fp32 MFMA 16x16x4, exact fp32 FMA chains): the layers are evaluated TRANSPOSED,
 //   H1^T[16 x 16pts] = W1[16 x 64] . feat^T[64 x 16pts],
-// so that (i) the gathered registers are the B operand as they stand (B[k][col]: col = l & 15 = point,
-// k-slot = l >> 4 = q) with the K index permuted to  k(ks, q) = level*32 + 8q + i,  ks = level*8 + i,
+// so that (i) the gathered registers are the B operand (B[k][col]: col = l & 15 = point, k-slot = l >> 4 = q) with
+// the K index permuted to  k(ks, q) = level*32 + ch(q, i),  ks = level*8 + i,  ch(q, i) = i < 4 ? 4q+i : 12+4q+i,
 // and the A operand W1[j = l & 15][k(ks, q)] is read from LDS in that same permutation; and (ii) each layer's
 // accumulator (rows 4q+reg, col = point) is directly the next layer's B operand with k(ks, q) = 4q + ks.
 // The output layer is zero-padded to 16 rows and block b's copy of it is placed at rows 4b..4b+3, all four blocks
@@ -20,6 +26,9 @@
 // No LDS round trip and no cross-lane shuffle anywhere between the gather and the per-point epilogue.
 #pragma once
 #include "eslam_common.h"
+
+// channel i (0..7) of piece g of a 32-channel texel: 4g..4g+3, then 16+4g..16+4g+3
+__device__ __forceinline__ int piece_channel(int g, int i) { return i < 4 ? 4 * g + i : 12 + 4 * g + i; }
 
 template <bool CL>
 __device__ __forceinline__ void gather8(const eslam_plane_t& P, float u, float v, int q, float acc[8]) {
@@ -36,12 +45,12 @@ __device__ __forceinline__ void gather8(const eslam_plane_t& P, float u, float v
     const unsigned c0 = ax.i0 * sx, c1 = ax.i1 * sx;
     const float* __restrict__ data = P.data;
     if (CL) {
-        const unsigned q8 = 8u * q;
-        const unsigned o00 = r0 + c0 + q8, o01 = r0 + c1 + q8, o10 = r1 + c0 + q8, o11 = r1 + c1 + q8;
-        const float4_t a00 = *(const float4_t*)(data + o00), b00 = *(const float4_t*)(data + o00 + 4u);
-        const float4_t a01 = *(const float4_t*)(data + o01), b01 = *(const float4_t*)(data + o01 + 4u);
-        const float4_t a10 = *(const float4_t*)(data + o10), b10 = *(const float4_t*)(data + o10 + 4u);
-        const float4_t a11 = *(const float4_t*)(data + o11), b11 = *(const float4_t*)(data + o11 + 4u);
+        const unsigned q4 = 4u * q;
+        const unsigned o00 = r0 + c0 + q4, o01 = r0 + c1 + q4, o10 = r1 + c0 + q4, o11 = r1 + c1 + q4;
+        const float4_t a00 = *(const float4_t*)(data + o00), b00 = *(const float4_t*)(data + o00 + 16u);
+        const float4_t a01 = *(const float4_t*)(data + o01), b01 = *(const float4_t*)(data + o01 + 16u);
+        const float4_t a10 = *(const float4_t*)(data + o10), b10 = *(const float4_t*)(data + o10 + 16u);
+        const float4_t a11 = *(const float4_t*)(data + o11), b11 = *(const float4_t*)(data + o11 + 16u);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             acc[i] += a00[i] * w00 + a01[i] * w01 + a10[i] * w10 + a11[i] * w11;
@@ -49,10 +58,9 @@ __device__ __forceinline__ void gather8(const eslam_plane_t& P, float u, float v
         }
     } else {
         const unsigned sc = (unsigned)P.stride_c;
-        const unsigned qo = 8u * q * sc;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const unsigned co = qo + i * sc;
+            const unsigned co = (unsigned)piece_channel(q, i) * sc;
             acc[i] += data[co + r0 + c0] * w00 + data[co + r0 + c1] * w01 + data[co + r1 + c0] * w10 +
                       data[co + r1 + c1] * w11;
         }
@@ -61,7 +69,7 @@ __device__ __forceinline__ void gather8(const eslam_plane_t& P, float u, float v
 
 // Per-decoder MFMA operand fragments, read from the LDS weight image (eslam_common.h layout).
 struct DecFrag {
-    float w1[16];     // W1[r][lvl*32 + 8q + i], index lvl*8 + i
+    float w1[16];     // W1[r][lvl*32 + piece_channel(q, i)], index lvl*8 + i
     float4_t w2;      // W2[r][4q .. 4q+3]
     float4_t w3;      // W3pad[r & 3][4q .. 4q+3]
     float4_t b1, b2;  // b[4q .. 4q+3]
@@ -71,8 +79,8 @@ struct DecFrag {
 __device__ __forceinline__ void load_dec_frag(DecFrag& f, const float* L, int r, int q) {
 #pragma unroll
     for (int lvl = 0; lvl < 2; ++lvl) {
-        const float4_t a = *(const float4_t*)(L + DEC_W1 + r * 64 + lvl * 32 + 8 * q);
-        const float4_t b = *(const float4_t*)(L + DEC_W1 + r * 64 + lvl * 32 + 8 * q + 4);
+        const float4_t a = *(const float4_t*)(L + DEC_W1 + r * 64 + lvl * 32 + 4 * q);
+        const float4_t b = *(const float4_t*)(L + DEC_W1 + r * 64 + lvl * 32 + 16 + 4 * q);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             f.w1[lvl * 8 + i] = a[i];
@@ -137,12 +145,12 @@ __device__ __forceinline__ void issue_taps(const eslam_plane_t& P, float u, floa
     const unsigned r0 = ay.i0 * sy, r1 = ay.i1 * sy;
     const unsigned c0 = ax.i0 * sx, c1 = ax.i1 * sx;
     const float* __restrict__ data = P.data;
-    const unsigned q8 = 8u * q;
-    const unsigned o00 = r0 + c0 + q8, o01 = r0 + c1 + q8, o10 = r1 + c0 + q8, o11 = r1 + c1 + q8;
-    t.a00 = *(const float4_t*)(data + o00); t.b00 = *(const float4_t*)(data + o00 + 4u);
-    t.a01 = *(const float4_t*)(data + o01); t.b01 = *(const float4_t*)(data + o01 + 4u);
-    t.a10 = *(const float4_t*)(data + o10); t.b10 = *(const float4_t*)(data + o10 + 4u);
-    t.a11 = *(const float4_t*)(data + o11); t.b11 = *(const float4_t*)(data + o11 + 4u);
+    const unsigned q4 = 4u * q;
+    const unsigned o00 = r0 + c0 + q4, o01 = r0 + c1 + q4, o10 = r1 + c0 + q4, o11 = r1 + c1 + q4;
+    t.a00 = *(const float4_t*)(data + o00); t.b00 = *(const float4_t*)(data + o00 + 16u);
+    t.a01 = *(const float4_t*)(data + o01); t.b01 = *(const float4_t*)(data + o01 + 16u);
+    t.a10 = *(const float4_t*)(data + o10); t.b10 = *(const float4_t*)(data + o10 + 16u);
+    t.a11 = *(const float4_t*)(data + o11); t.b11 = *(const float4_t*)(data + o11 + 16u);
 }
 
 __device__ __forceinline__ void accumulate_taps(const PlaneTaps& t, float acc[8]) {
@@ -190,9 +198,9 @@ __device__ __forceinline__ void gather_features(const PlaneSet& planes, int d, f
     }
 }
 
-// store the lane's 16 gathered features of decoder d for point `pt` into feat_out [N,128]
+// store the lane's 16 features (piece q of both levels) of decoder d for point `pt` into feat_out [N,128]
 __device__ __forceinline__ void store_features(float* feat_out, int64_t pt, int d, int q, const float feat[16]) {
-    float* dst = feat_out + pt * 128 + d * 64 + 8 * q;
+    float* dst = feat_out + pt * 128 + d * 64 + 4 * q;
 #pragma unroll
     for (int lvl = 0; lvl < 2; ++lvl) {
         float4_t a, b;
@@ -202,6 +210,42 @@ __device__ __forceinline__ void store_features(float* feat_out, int64_t pt, int 
             b[i] = feat[lvl * 8 + 4 + i];
         }
         *(float4_t*)(dst + lvl * 32) = a;
-        *(float4_t*)(dst + lvl * 32 + 4) = b;
+        *(float4_t*)(dst + lvl * 32 + 16) = b;
     }
+}
+
+// the same 16 values read back (backward pass), gather role
+__device__ __forceinline__ void load_features(const float* feat_in, int64_t pt, int d, int q, float feat[16]) {
+    const float* src = feat_in + pt * 128 + d * 64 + 4 * q;
+#pragma unroll
+    for (int lvl = 0; lvl < 2; ++lvl) {
+        const float4_t a = *(const float4_t*)(src + lvl * 32), b = *(const float4_t*)(src + lvl * 32 + 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            feat[lvl * 8 + i] = a[i];
+            feat[lvl * 8 + 4 + i] = b[i];
+        }
+    }
+}
+
+// Lane roles (see the top of this file).  CL = channels-last planes.
+template <bool CL> __device__ __forceinline__ int gather_point(int lane) { return CL ? lane >> 2 : lane & 15; }
+template <bool CL> __device__ __forceinline__ int gather_piece(int lane) { return CL ? lane & 3 : lane >> 4; }
+
+// gather role -> MFMA role: lane 16q + r takes the registers of lane 4r + q
+template <bool CL, int NREG>
+__device__ __forceinline__ void to_mfma_role(float v[NREG], int lane) {
+    if (!CL) return;
+    const int src = (((lane & 15) << 2) | (lane >> 4)) << 2;
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) v[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v[i])));
+}
+
+// MFMA role -> gather role: lane 4p + g takes the registers of lane 16g + p
+template <bool CL, int NREG>
+__device__ __forceinline__ void to_gather_role(float v[NREG], int lane) {
+    if (!CL) return;
+    const int src = (((lane & 3) << 4) | (lane >> 2)) << 2;
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) v[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v[i])));
 }

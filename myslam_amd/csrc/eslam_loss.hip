@@ -68,36 +68,21 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
                                                         const float* __restrict__ upstream) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ray = blockIdx.x * 4 + wave;
-    const float nf = acc[A_N_FRONT], nc = acc[A_N_CENTER], nt = acc[A_N_TAIL], nd = acc[A_N_DEPTH], ncol = acc[A_N_COLOR];
-    LossW w = w_in;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && loss) {
-        // torch.mean over an empty set is NaN (0/0); keep that behaviour
-        loss[0] = w.fs * (acc[A_S_FRONT] / nf) + w.center * (acc[A_S_CENTER] / nc) + w.tail * (acc[A_S_TAIL] / nt) +
-                  w.color * (acc[A_S_COLOR] / ncol) + w.depth * (acc[A_S_DEPTH] / nd);
-    }
+    const float nd = acc[A_N_DEPTH], ncol = acc[A_N_COLOR];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && loss) loss[0] = loss_value_from_acc(w_in, acc);
     if (ray >= R || !g_sdf) return;
-    if (upstream) {
-        const float u = upstream[0];
-        w.fs *= u; w.center *= u; w.tail *= u; w.depth *= u; w.color *= u;
-    }
+    const LossW w = loss_scaled_weights(w_in, upstream);
     const float d = gt_depth[ray];
     const bool mc = ray_mask ? (ray_mask[ray] != 0) : true;
     const bool m = mc && d > 0.0f;
-    const float kf = 2.0f * w.fs / nf, kc = 2.0f * w.center * tr.t / nc, kt = 2.0f * w.tail * tr.t / nt;
+    const LossK k = loss_sdf_factors(w, tr, acc);
     for (int s = lane; s < S; s += WAVE) {
-        float g = 0.0f;
-        if (m) {
-            const float z = z_vals[(int64_t)ray * S + s];
-            const float sd = sdf[(int64_t)ray * S + s];
-            const int reg = sdf_region(z, d, tr);
-            if (reg == 0) g = kf * (sd - 1.0f);
-            else if (reg == 1) g = kc * ((z + sd * tr.t) - d);
-            else if (reg == 2) g = kt * ((z + sd * tr.t) - d);
-        }
-        g_sdf[(int64_t)ray * S + s] = g;
+        float z = 0.0f, sd = 0.0f;
+        if (m) { z = z_vals[(int64_t)ray * S + s]; sd = sdf[(int64_t)ray * S + s]; }
+        g_sdf[(int64_t)ray * S + s] = loss_g_sdf(m, z, sd, d, tr, k);
     }
-    if (lane == 0) g_depth[ray] = m ? -2.0f * w.depth * (d - depth[ray]) / nd : 0.0f;
-    if (lane < 3) g_rgb[3 * ray + lane] = mc ? -2.0f * w.color * (gt_color[3 * ray + lane] - rgb[3 * ray + lane]) / ncol : 0.0f;
+    if (lane == 0) g_depth[ray] = loss_g_depth(m, d, depth[ray], w, nd);
+    if (lane < 3) g_rgb[3 * ray + lane] = loss_g_color(mc, gt_color[3 * ray + lane], rgb[3 * ray + lane], w, ncol);
 }
 
 static int loss_args_ok(const char* who, const float* depth, const float* rgb, const float* sdf, const float* z_vals,

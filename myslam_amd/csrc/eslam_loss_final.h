@@ -24,6 +24,59 @@ __device__ __forceinline__ int sdf_region(float z, float d, Trunc tr) {
     return 2;
 }
 
+// Upstream gradients of the loss for one ray / one sample, shared by loss_grad_kernel and by the backward kernel that forms
+// them inline (eslam_render_bwd_loss): same expressions, so both paths give the same bits.
+struct LossGradIn {
+    const float* gt_depth;       // [R]
+    const float* gt_color;       // [R,3]
+    const uint8_t* ray_mask;     // [R] or NULL
+    const float* depth;          // [R]   forward outputs
+    const float* rgb;            // [R,3]
+    const float* acc;            // [ESLAM_LOSS_ACC] set sizes and sums (global, i.e. after any all-reduce)
+    const float* upstream;       // [1] d L / d loss, or NULL (= 1)
+    float* loss_out;             // [1] or NULL: the loss value formed from acc
+    Trunc tr;
+    LossW w;
+};
+
+__device__ __forceinline__ LossW loss_scaled_weights(const LossW w_in, const float* __restrict__ upstream) {
+    LossW w = w_in;
+    if (upstream) {
+        const float u = upstream[0];
+        w.fs *= u; w.center *= u; w.tail *= u; w.depth *= u; w.color *= u;
+    }
+    return w;
+}
+
+struct LossK { float kf, kc, kt; };
+__device__ __forceinline__ LossK loss_sdf_factors(const LossW w, const Trunc tr, const float* __restrict__ acc) {
+    return LossK{2.0f * w.fs / acc[A_N_FRONT], 2.0f * w.center * tr.t / acc[A_N_CENTER], 2.0f * w.tail * tr.t / acc[A_N_TAIL]};
+}
+
+// d loss / d sdf of one sample of a ray with depth d (m: the ray takes part in the SDF terms)
+__device__ __forceinline__ float loss_g_sdf(bool m, float z, float sd, float d, const Trunc tr, const LossK k) {
+    float g = 0.0f;
+    if (m) {
+        const int reg = sdf_region(z, d, tr);
+        if (reg == 0) g = k.kf * (sd - 1.0f);
+        else if (reg == 1) g = k.kc * ((z + sd * tr.t) - d);
+        else if (reg == 2) g = k.kt * ((z + sd * tr.t) - d);
+    }
+    return g;
+}
+__device__ __forceinline__ float loss_g_depth(bool m, float d, float depth, const LossW w, float nd) {
+    return m ? -2.0f * w.depth * (d - depth) / nd : 0.0f;
+}
+__device__ __forceinline__ float loss_g_color(bool mc, float gt, float c, const LossW w, float ncol) {
+    return mc ? -2.0f * w.color * (gt - c) / ncol : 0.0f;
+}
+__device__ __forceinline__ float loss_value_from_acc(const LossW w, const float* __restrict__ acc) {
+    // torch.mean over an empty set is NaN (0/0); keep that behaviour
+    return w.fs * (acc[A_S_FRONT] / acc[A_N_FRONT]) + w.center * (acc[A_S_CENTER] / acc[A_N_CENTER]) +
+           w.tail * (acc[A_S_TAIL] / acc[A_N_TAIL]) + w.color * (acc[A_S_COLOR] / acc[A_N_COLOR]) +
+           w.depth * (acc[A_S_DEPTH] / acc[A_N_DEPTH]);
+}
+
 // Called by ALL threads of a workgroup (>= 64 threads); `tot` = this workgroup's sum of accumulator threadIdx.x (threads
 // 0 .. A_COUNT-1).  scratch: [0] ticket counter (unsigned); accumulator k at scratch[32 * (k + 1)] - one 128-B line each,
 // so the float atomics of different accumulators go to different memory channels.  Everything is exchanged through

@@ -8,6 +8,7 @@
 //   coord_bwd_kernel       optional: gradient w.r.t. the sample position -> rays_o / rays_d (pose) or points
 #include <stdlib.h>
 #include "eslam_decode_tile.h"
+#include "eslam_loss_final.h"
 
 #define SLAB 1364          // floats per decoder per wave slab (rgb decoder needs 1363)
 // offsets inside a per-decoder slab
@@ -19,108 +20,49 @@
 #define SL_B3 1360         // [nout]
 
 // ---------------------------------------------------------------------------------------------------------
-// composite backward: autograd of reference src/utils/Renderer.py:140-153
+// composite backward (autograd of reference src/utils/Renderer.py:140-153), one 64-sample chunk of one ray, sample role
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void composite_bwd_kernel(const float* __restrict__ z_vals,
-                                                            const float* __restrict__ sdf_in,
-                                                            const float* __restrict__ raw_rgb,
-                                                            const float* __restrict__ beta_p,
-                                                            const float* __restrict__ g_depth,
-                                                            const float* __restrict__ g_rgb,
-                                                            const float* __restrict__ g_sdf, int R, int S,
-                                                            float* __restrict__ g_o, float* __restrict__ g_beta) {
-    // g_beta here is the per-workgroup partial buffer [gridDim.x]
-    // g_beta: every workgroup writes one partial sum (summed later by dec_grad_reduce_kernel).  One atomic per ray on
-    // the single address of g_beta serialises at the memory side: 4096 of them cost 50 us.
-    __shared__ float beta_part[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ray = blockIdx.x * 4 + wave;
-    if (lane == 0) beta_part[wave] = 0.0f;
-    if (ray < R) {
-    const float beta = beta_p[0];
-    const float gd = g_depth ? g_depth[ray] : 0.0f;
-    const float gr = g_rgb ? g_rgb[3 * ray + 0] : 0.0f;
-    const float gg = g_rgb ? g_rgb[3 * ray + 1] : 0.0f;
-    const float gb = g_rgb ? g_rgb[3 * ray + 2] : 0.0f;
-    const int64_t base = (int64_t)ray * S;
-    const int nchunk = (S + WAVE - 1) / WAVE;
+// Upstream of a ray: d L / d depth, d L / d rgb (gd, gr, gg, gb); per sample d L / d sdf (g_sdf_s).  Returns the
+// pre-activation output gradients of the sample (o[0..2] colour, o[3] sdf) and adds to gbeta_acc.  `carry` is the suffix
+// sum of gw*w over the LATER chunks (chunks are visited last to first), `trans_in` the transmittance entering the chunk.
+struct RayUp { float gd, gr, gg, gb; };
 
-    // pass A: transmittance product of every chunk
-    float chunk_prod[ESLAM_MAX_SAMPLES / WAVE];
-#pragma unroll
-    for (int c = 0; c < ESLAM_MAX_SAMPLES / WAVE; ++c) {
-        chunk_prod[c] = 1.0f;
-        if (c < nchunk) {
-            const int s = c * WAVE + lane;
-            float fac = 1.0f;
-            if (s < S) {
-                const float sd = sdf_in[base + s];
-                const float alpha = 1.0f - expf(-beta * sigmoidf_(-sd * beta));
-                fac = (1.0f - alpha) + 1e-10f;
-            }
-            chunk_prod[c] = __shfl(wave_incl_prod(fac, lane), 63, WAVE);
-        }
+__device__ __forceinline__ float4_t composite_bwd_chunk(const RayUp up, float beta, bool valid, float sd, float z, float cr,
+                                                        float cg, float cb, float g_sdf_s, float trans_in, float& carry,
+                                                        float& gbeta_acc, int lane) {
+    const float sg = sigmoidf_(-sd * beta);
+    const float e = expf(-beta * sg);
+    const float alpha = valid ? 1.0f - e : 0.0f;
+    const float fac = valid ? (1.0f - alpha) + 1e-10f : 1.0f;
+    const float pin = wave_incl_prod(fac, lane);
+    float pex = __shfl_up(pin, 1, WAVE);
+    if (lane == 0) pex = 1.0f;
+    const float T = trans_in * pex;
+    const float w = alpha * T;
+    const float gw = up.gd * z + up.gr * cr + up.gg * cg + up.gb * cb;
+    const float v = valid ? gw * w : 0.0f;
+    // exclusive suffix sum_{k>i} gw_k w_k, formed WITHOUT subtracting v_i from an inclusive sum: w decays
+    // geometrically along the ray, so (inclusive - own) would lose the small tail in the rounding of the
+    // dominant own term, and g_alpha is itself a cancelling difference of two terms of the size of gw.
+    float vn = __shfl_down(v, 1, WAVE);
+    if (lane == WAVE - 1) vn = 0.0f;
+    const float after_local = wave_incl_suffix_sum(vn, lane);
+    const float after = after_local + carry;
+    const float g_alpha = gw * T - after / fac;
+    carry += __shfl(after_local, 0, WAVE) + __shfl(v, 0, WAVE);
+    float4_t o = (float4_t){0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+        const float ds = sg * (1.0f - sg);                // sigmoid'
+        const float dalpha_dsdf = -beta * beta * e * ds;
+        const float dalpha_dbeta = e * (sg - beta * ds * sd);
+        gbeta_acc += g_alpha * dalpha_dbeta;
+        const float g_sdf_tot = g_sdf_s + g_alpha * dalpha_dsdf;
+        o[0] = w * up.gr * cr * (1.0f - cr);
+        o[1] = w * up.gg * cg * (1.0f - cg);
+        o[2] = w * up.gb * cb * (1.0f - cb);
+        o[3] = g_sdf_tot * (1.0f - sd * sd);
     }
-    // pass B: chunks in reverse, carrying the suffix sum of gw*w
-    float carry = 0.0f;
-    float gbeta_acc = 0.0f;
-#pragma unroll
-    for (int c = ESLAM_MAX_SAMPLES / WAVE - 1; c >= 0; --c) {
-        if (c < nchunk) {
-            float trans_in = 1.0f;
-#pragma unroll
-            for (int k = 0; k < ESLAM_MAX_SAMPLES / WAVE; ++k)
-                if (k < c) trans_in *= chunk_prod[k];
-            const int s = c * WAVE + lane;
-            const bool valid = s < S;
-            const float sd = valid ? sdf_in[base + s] : 0.0f;
-            const float z = valid ? z_vals[base + s] : 0.0f;
-            float cr = 0.f, cg = 0.f, cb = 0.f;
-            if (valid) {
-                cr = raw_rgb[(base + s) * 3 + 0];
-                cg = raw_rgb[(base + s) * 3 + 1];
-                cb = raw_rgb[(base + s) * 3 + 2];
-            }
-            const float sg = sigmoidf_(-sd * beta);
-            const float e = expf(-beta * sg);
-            const float alpha = valid ? 1.0f - e : 0.0f;
-            const float fac = valid ? (1.0f - alpha) + 1e-10f : 1.0f;
-            const float pin = wave_incl_prod(fac, lane);
-            float pex = __shfl_up(pin, 1, WAVE);
-            if (lane == 0) pex = 1.0f;
-            const float T = trans_in * pex;
-            const float w = alpha * T;
-            const float gw = gd * z + gr * cr + gg * cg + gb * cb;
-            const float v = valid ? gw * w : 0.0f;
-            // exclusive suffix sum_{k>i} gw_k w_k, formed WITHOUT subtracting v_i from an inclusive sum: w decays
-            // geometrically along the ray, so (inclusive - own) would lose the small tail in the rounding of the
-            // dominant own term, and g_alpha is itself a cancelling difference of two terms of the size of gw.
-            float vn = __shfl_down(v, 1, WAVE);
-            if (lane == WAVE - 1) vn = 0.0f;
-            const float after_local = wave_incl_suffix_sum(vn, lane);
-            const float after = after_local + carry;
-            const float g_alpha = gw * T - after / fac;
-            carry += __shfl(after_local, 0, WAVE) + __shfl(v, 0, WAVE);
-            if (valid) {
-                const float ds = sg * (1.0f - sg);                // sigmoid'
-                const float dalpha_dsdf = -beta * beta * e * ds;
-                const float dalpha_dbeta = e * (sg - beta * ds * sd);
-                gbeta_acc += g_alpha * dalpha_dbeta;
-                const float g_sdf_tot = (g_sdf ? g_sdf[base + s] : 0.0f) + g_alpha * dalpha_dsdf;
-                float4_t o;
-                o[0] = w * gr * cr * (1.0f - cr);
-                o[1] = w * gg * cg * (1.0f - cg);
-                o[2] = w * gb * cb * (1.0f - cb);
-                o[3] = g_sdf_tot * (1.0f - sd * sd);
-                *(float4_t*)(g_o + (base + s) * 4) = o;
-            }
-        }
-    }
-    const float tot = wave_sum(gbeta_acc);
-    if (lane == 0) beta_part[wave] = tot;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) g_beta[blockIdx.x] = (beta_part[0] + beta_part[1]) + (beta_part[2] + beta_part[3]);
+    return o;
 }
 
 // decode-mode variant: g_o = g_raw * activation'(raw)      (autograd of decoders.py:103,123)
@@ -139,15 +81,36 @@ __global__ void decode_act_bwd_kernel(const float* __restrict__ raw, const float
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// decoder MLP backward (autograd of reference src/networks/decoders.py:97-103 / 117-123)
+// decoder MLP backward (autograd of reference src/networks/decoders.py:97-103 / 117-123), with the composite backward
+// and - when the loss is the fused mapping loss - the loss gradient formed in the same wave
 // ---------------------------------------------------------------------------------------------------------
 #define TP 20                      // row pitch (floats) of the 16x16 transpose tiles: conflict-free, 16-B aligned
+
+struct RayBwdIn {                  // MODE >= 1: what the composite backward of a ray reads
+    const float* z_vals;           // [R,S]
+    const float* sdf;              // [R,S]   tanh outputs of the forward pass
+    const float* raw_rgb;          // [R,S,3] sigmoid outputs
+    const float* beta;             // [1]
+    const float* g_depth;          // [R]   upstream, any of the three may be NULL (= 0); with MODE 2 they are ADDED to the
+    const float* g_rgb;            // [R,3] loss's own gradients
+    const float* g_sdf;            // [R,S]
+    float* beta_parts;             // [gridDim.x] partial sums of g_beta (written by the sdf decoder's workgroups)
+    int R, S;
+};
+
+// MODE 0: tiles of 64 free points, pre-activation output gradients g_o [N,4] from memory (decode_act_bwd_kernel).
+// MODE 1: a wave owns a RAY: it runs the composite backward of its chunks (upstream gradients from memory) and feeds the
+//         result to the MLP backward from registers - the sample role of the one IS the B operand of the other.  Both
+//         decoders' workgroups (blockIdx.y) repeat the scalar composite work; neither writes g_o.
+// MODE 2: as 1, and the upstream gradients are those of the mapping loss (src/Mapper.py:110-144,337-346), formed here from
+//         the global set sizes in li.acc: loss gradient, composite backward and decoder backward are ONE launch.
 // WGRAD = false: decoders are frozen (tracking, reference src/Tracker.py:111-112): only g_feat is produced, the
 // parameter-gradient contractions (28 of the 68 MFMAs per block), their LDS transposes and the slabs are skipped.
-template <bool WGRAD>
-__global__ __launch_bounds__(256) void mlp_bwd_kernel(const eslam_decoders_t dec, const float* __restrict__ feat,
+template <int MODE, bool WGRAD>
+__global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t dec, const float* __restrict__ feat,
                                                       const float* __restrict__ g_o, int64_t N,
-                                                      float* __restrict__ g_feat, float* __restrict__ slabs) {
+                                                      float* __restrict__ g_feat, float* __restrict__ slabs,
+                                                      const RayBwdIn rb, const LossGradIn li) {
     __shared__ __attribute__((aligned(16))) float wlds[2 * DEC_LDS];
     __shared__ __attribute__((aligned(16))) float tiles[4][4][16 * TP];   // per wave: gz1, gz2, h1, h2 (as [pt][j])
     __shared__ __attribute__((aligned(16))) float gtile[4][64 * 4];       // per wave: g_o of the tile [pt][o]
@@ -158,7 +121,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const eslam_decoders_t dec
     const int nout = d ? 3 : 1;
     const float* L = wlds + d * DEC_LDS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 15, q = lane >> 4;
+    const int r = lane & 15, q = lane >> 4;           // MFMA role
+    const int gp = lane >> 2, gq = lane & 3;          // gather role: feat / g_feat rows are read and written a quad per row
     float* tz1 = tiles[wave][0];
     float* tz2 = tiles[wave][1];
     float* th1 = tiles[wave][2];
@@ -173,10 +137,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const eslam_decoders_t dec
         w3col[ks] = L[DEC_W3 + ks * 16 + r];                    // W3pad[o = ks][j = r]
         w2t[ks] = L[DEC_W2 + (4 * q + ks) * 16 + r];            // W2[j = 4q+ks][k' = r]
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-            const int fidx = (mb >> 1) * 32 + 8 * (r >> 2) + 4 * (mb & 1) + (r & 3);
-            w1t[mb][ks] = L[DEC_W1 + (4 * q + ks) * 64 + fidx]; // W1[j = 4q+ks][f(mb, r)]
-        }
+        for (int mb = 0; mb < 4; ++mb)                          // row r of row block mb <-> feature (mb>>1)*32 + 16*(mb&1) + r:
+            w1t[mb][ks] = L[DEC_W1 + (4 * q + ks) * 64 + (mb >> 1) * 32 + 16 * (mb & 1) + r];   // lane q then holds piece q
     }
 
     float4_t gW1[4], gW2, gW3, gb1, gb2;
@@ -184,33 +146,25 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const eslam_decoders_t dec
     for (int i = 0; i < 4; ++i) gW1[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
     gW2 = gW3 = gb1 = gb2 = (float4_t){0.f, 0.f, 0.f, 0.f};
     float gb3[3] = {0.f, 0.f, 0.f};
+    float gbeta_acc = 0.0f;
 
-    const int64_t ntiles = (N + 63) / 64;
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
-        const int64_t p0 = tile * 64;
-        const int nvalid = (int)min((int64_t)64, N - p0);
+    // MLP backward of one tile of <= 64 points starting at point p0; go[] = this decoder's pre-activation output
+    // gradients of the lane's point (sample role)
+    auto tile_bwd = [&](const int64_t p0, const int nvalid, const float go[4]) {
         const int nblk = (nvalid + 15) >> 4;
-
-        // sample role: pre-activation output gradients of this decoder
-        float go[4] = {0.f, 0.f, 0.f, 0.f};
-        if (lane < nvalid) {
-            const float4_t g = *(const float4_t*)(g_o + (p0 + lane) * 4);
-            if (d == 0) go[0] = g[3];
-            else { go[0] = g[0]; go[1] = g[1]; go[2] = g[2]; }
-        }
 #pragma unroll
         for (int o = 0; o < 3; ++o) gb3[o] += go[o];
         *(float4_t*)(gt + lane * 4) = (float4_t){go[0], go[1], go[2], go[3]};
 
-        // block role: features of point 16b + r (gather layout, 8 channels per level).  The rows of block b+1 are
-        // requested before block b is computed: at 2 waves per SIMD nothing else hides the ~2k-cycle load latency.
+        // gather role: the 16 features of point 16b + gp, piece gq.  The rows of block b+1 are requested before block b is
+        // computed: at 2 waves per SIMD nothing else hides the ~2k-cycle load latency.
         auto load_block = [&](int b, float4_t v[4]) {
-            const int64_t pt = min(p0 + 16 * b + r, N - 1);
-            const float* fp = feat + pt * 128 + d * 64 + 8 * q;
+            const int64_t pt = min(p0 + 16 * b + gp, N - 1);
+            const float* fp = feat + pt * 128 + d * 64 + 4 * gq;
             v[0] = *(const float4_t*)(fp);
-            v[1] = *(const float4_t*)(fp + 4);
+            v[1] = *(const float4_t*)(fp + 16);
             v[2] = *(const float4_t*)(fp + 32);
-            v[3] = *(const float4_t*)(fp + 36);
+            v[3] = *(const float4_t*)(fp + 48);
         };
         float4_t fnext[4];
         load_block(0, fnext);
@@ -232,6 +186,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const eslam_decoders_t dec
                     fbk[ks] = *(const float4_t*)(feat + pk * 128 + d * 64 + 4 * r);
                 }
             }
+            to_mfma_role<true, 16>(ft, lane);
             float4_t h1, h2;
             mlp_hidden(f, ft, h1, h2);
 
@@ -253,7 +208,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const eslam_decoders_t dec
             gb1 += gz1;
             gb2 += gz2;
 
-            // g_feat^T = W1^T . g_z1^T, four row blocks permuted so that lane (r,q) receives channels 8q..8q+7
+            // g_feat^T = W1^T . g_z1^T, four row blocks ordered so that MFMA-role lane (r, q) receives piece q of point r
             float gf[16];
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
@@ -263,7 +218,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const eslam_decoders_t dec
 #pragma unroll
                 for (int i = 0; i < 4; ++i) gf[(mb >> 1) * 8 + 4 * (mb & 1) + i] = acc[i];
             }
-            if (p0 + 16 * b + r < N) store_features(g_feat, p0 + 16 * b + r, d, q, gf);
+            to_gather_role<true, 16>(gf, lane);
+            if (p0 + 16 * b + gp < p0 + nvalid) store_features(g_feat, p0 + 16 * b + gp, d, gq, gf);
             if (!WGRAD) continue;
 
             // transposes through LDS: D layout (rows 4q+reg, col = point r) -> [point][row]
@@ -297,6 +253,95 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const eslam_decoders_t dec
             }
             WAVE_SYNC();
         }
+    };
+
+    if (MODE == 0) {
+        const int64_t ntiles = (N + 63) / 64;
+        for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+            const int64_t p0 = tile * 64;
+            const int nvalid = (int)min((int64_t)64, N - p0);
+            // sample role: pre-activation output gradients of this decoder
+            float go[4] = {0.f, 0.f, 0.f, 0.f};
+            if (lane < nvalid) {
+                const float4_t g = *(const float4_t*)(g_o + (p0 + lane) * 4);
+                if (d == 0) go[0] = g[3];
+                else { go[0] = g[0]; go[1] = g[1]; go[2] = g[2]; }
+            }
+            tile_bwd(p0, nvalid, go);
+        }
+    } else {
+        const int R = rb.R, S = rb.S;
+        const int nchunk = (S + WAVE - 1) / WAVE;
+        const float beta = rb.beta[0];
+        LossW lw = {};
+        LossK lk = {};
+        float nd = 1.0f, ncol = 1.0f;
+        if (MODE == 2) {
+            lw = loss_scaled_weights(li.w, li.upstream);
+            lk = loss_sdf_factors(lw, li.tr, li.acc);
+            nd = li.acc[A_N_DEPTH]; ncol = li.acc[A_N_COLOR];
+            if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && li.loss_out)
+                li.loss_out[0] = loss_value_from_acc(li.w, li.acc);
+        }
+        for (int ray = blockIdx.x * 4 + wave; ray < R; ray += gridDim.x * 4) {
+            const int64_t base = (int64_t)ray * S;
+            RayUp up;
+            up.gd = rb.g_depth ? rb.g_depth[ray] : 0.0f;
+            up.gr = rb.g_rgb ? rb.g_rgb[3 * ray + 0] : 0.0f;
+            up.gg = rb.g_rgb ? rb.g_rgb[3 * ray + 1] : 0.0f;
+            up.gb = rb.g_rgb ? rb.g_rgb[3 * ray + 2] : 0.0f;
+            float gtd = 0.0f;
+            bool m = false;
+            if (MODE == 2) {
+                gtd = li.gt_depth[ray];
+                const bool mc = li.ray_mask ? (li.ray_mask[ray] != 0) : true;
+                m = mc && gtd > 0.0f;
+                up.gd += loss_g_depth(m, gtd, li.depth[ray], lw, nd);
+                up.gr += loss_g_color(mc, li.gt_color[3 * ray + 0], li.rgb[3 * ray + 0], lw, ncol);
+                up.gg += loss_g_color(mc, li.gt_color[3 * ray + 1], li.rgb[3 * ray + 1], lw, ncol);
+                up.gb += loss_g_color(mc, li.gt_color[3 * ray + 2], li.rgb[3 * ray + 2], lw, ncol);
+            }
+            // pass A: transmittance product of every chunk; lane c keeps chunk c's
+            float myprod = 1.0f;
+            for (int c = 0; c < nchunk - 1; ++c) {           // (the last chunk's product is never needed)
+                const int s = c * WAVE + lane;               // chunks before the last are full
+                const float sd = rb.sdf[base + s];
+                const float alpha = 1.0f - expf(-beta * sigmoidf_(-sd * beta));
+                const float cp = __shfl(wave_incl_prod((1.0f - alpha) + 1e-10f, lane), 63, WAVE);
+                if (lane == c) myprod = cp;
+            }
+            // pass B: chunks in reverse, carrying the suffix sum of gw*w
+            float carry = 0.0f;
+            for (int c = nchunk - 1; c >= 0; --c) {
+                float trans_in = 1.0f;
+                for (int k = 0; k < c; ++k) trans_in *= __shfl(myprod, k, WAVE);
+                const int s = c * WAVE + lane;
+                const bool valid = s < S;
+                float sd = 0.f, z = 0.f, cr = 0.f, cg = 0.f, cb = 0.f, gs = 0.f;
+                if (valid) {
+                    sd = rb.sdf[base + s];
+                    z = rb.z_vals[base + s];
+                    cr = rb.raw_rgb[(base + s) * 3 + 0];
+                    cg = rb.raw_rgb[(base + s) * 3 + 1];
+                    cb = rb.raw_rgb[(base + s) * 3 + 2];
+                    if (rb.g_sdf) gs = rb.g_sdf[base + s];
+                    if (MODE == 2) gs += loss_g_sdf(m, z, sd, gtd, li.tr, lk);
+                }
+                const float4_t o = composite_bwd_chunk(up, beta, valid, sd, z, cr, cg, cb, gs, trans_in, carry, gbeta_acc, lane);
+                float go[4] = {0.f, 0.f, 0.f, 0.f};
+                if (d == 0) go[0] = o[3];
+                else { go[0] = o[0]; go[1] = o[1]; go[2] = o[2]; }
+                tile_bwd(base + c * WAVE, min(WAVE, S - c * WAVE), go);
+            }
+        }
+        // g_beta: one partial sum per workgroup of the sdf decoder (summed by dec_grad_reduce_kernel / beta_sum_kernel);
+        // one atomic per ray on the single address of g_beta would serialise at the memory side (4096 of them: 50 us)
+        __shared__ float beta_part[4];
+        const float tot = wave_sum(gbeta_acc);
+        if (lane == 0) beta_part[wave] = tot;
+        __syncthreads();
+        if (d == 0 && threadIdx.x == 0 && rb.beta_parts)
+            rb.beta_parts[blockIdx.x] = (beta_part[0] + beta_part[1]) + (beta_part[2] + beta_part[3]);
     }
 
     if (!WGRAD) return;
@@ -413,19 +458,20 @@ __global__ __launch_bounds__(1024) void dec_grad_reduce_kernel(const float* __re
 template <bool CL>
 __device__ __forceinline__ void coord_grad8(const eslam_plane_t& P, float u, float v, int q, const float g[8],
                                             float& gu, float& gv) {
+    // q: the lane's piece of the texel (gather role): channels piece_channel(q, 0..7)
     const AxisCoord ax = axis_coord(u, P.w);
     const AxisCoord ay = axis_coord(v, P.h);
     const int sy = (int)P.stride_y, sx = (int)P.stride_x, sc = (int)P.stride_c;
     const int r0 = ay.i0 * sy, r1 = ay.i1 * sy, c0 = ax.i0 * sx, c1 = ax.i1 * sx;
     float su = 0.f, sv = 0.f;
-    const float* base = P.data + 8 * q * sc;
     if (CL) {
+        const float* base = P.data + 4 * q;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-            const float4_t t00 = *(const float4_t*)(base + r0 + c0 + 4 * hh);
-            const float4_t t01 = *(const float4_t*)(base + r0 + c1 + 4 * hh);
-            const float4_t t10 = *(const float4_t*)(base + r1 + c0 + 4 * hh);
-            const float4_t t11 = *(const float4_t*)(base + r1 + c1 + 4 * hh);
+            const float4_t t00 = *(const float4_t*)(base + r0 + c0 + 16 * hh);
+            const float4_t t01 = *(const float4_t*)(base + r0 + c1 + 16 * hh);
+            const float4_t t10 = *(const float4_t*)(base + r1 + c0 + 16 * hh);
+            const float4_t t11 = *(const float4_t*)(base + r1 + c1 + 16 * hh);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 su += g[4 * hh + i] * ((t01[i] - t00[i]) * (1.0f - ay.t) + (t11[i] - t10[i]) * ay.t);
@@ -435,7 +481,7 @@ __device__ __forceinline__ void coord_grad8(const eslam_plane_t& P, float u, flo
     } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float* b = base + i * sc;
+            const float* b = P.data + piece_channel(q, i) * sc;
             const float t00 = b[r0 + c0], t01 = b[r0 + c1], t10 = b[r1 + c0], t11 = b[r1 + c1];
             su += g[i] * ((t01 - t00) * (1.0f - ay.t) + (t11 - t10) * ay.t);
             sv += g[i] * ((t10 - t00) * (1.0f - ax.t) + (t11 - t01) * ax.t);
@@ -456,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void coord_bwd_kernel(const PlaneSet planes
     // RENDER: one wave per ray, outputs g_rays_o/g_rays_d [R,3].
     // else:   one wave per 64 points (z_vals = pts [N,3], R = N), output g_rays_o = g_pts [N,3].
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 15, q = lane >> 4;
+    const int r = gather_point<CL>(lane), q = gather_piece<CL>(lane);     // gather role (eslam_decode_tile.h)
     const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
     const int64_t nunits = RENDER ? R : ((int64_t)R + 63) / 64;
     if (unit >= nunits) return;
@@ -490,8 +536,8 @@ __global__ __launch_bounds__(256, 2) void coord_bwd_kernel(const PlaneSet planes
         for (int d = 0; d < 2; ++d) {
 #pragma unroll
             for (int lvl = 0; lvl < 2; ++lvl) {
-                const float* gfp = g_feat + (base + sc_) * 128 + d * 64 + lvl * 32 + 8 * q;
-                const float4_t ga = *(const float4_t*)gfp, gb = *(const float4_t*)(gfp + 4);
+                const float* gfp = g_feat + (base + sc_) * 128 + d * 64 + lvl * 32 + 4 * q;
+                const float4_t ga = *(const float4_t*)gfp, gb = *(const float4_t*)(gfp + 16);
                 const float g[8] = {ga[0], ga[1], ga[2], ga[3], gb[0], gb[1], gb[2], gb[3]};
 #pragma unroll
                 for (int o = 0; o < 3; ++o) {
@@ -507,8 +553,8 @@ __global__ __launch_bounds__(256, 2) void coord_bwd_kernel(const PlaneSet planes
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             float v = gp[k];
-            v += __shfl_xor(v, 16, WAVE);           // sum the four channel octets
-            v += __shfl_xor(v, 32, WAVE);
+            v += __shfl_xor(v, CL ? 1 : 16, WAVE);  // sum the four pieces of the point
+            v += __shfl_xor(v, CL ? 2 : 32, WAVE);
             v = valid ? v * sc3[k] : 0.0f;
             if (RENDER) {
                 if (q == 0) { go_acc[k] += v; gd_acc[k] += v * zz; }
@@ -557,7 +603,7 @@ static int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
 // workspace layout: g_o [n,4] | g_feat [n,128] | slabs [MLP_BWD_MAX_WG*4][2][SLAB] + g_beta partials [n/4 + 1] |
 //                   ray order [n] (int)
 static int64_t slab_region_bytes(int64_t n_points) {
-    return ((int64_t)MLP_BWD_MAX_WG * 4 * 2 * SLAB + n_points / 4 + 1) * 4;
+    return ((int64_t)MLP_BWD_MAX_WG * 4 * 2 * SLAB + n_points / 4 + 1) * 4;      // (g_beta partials need MLP_BWD_MAX_WG only)
 }
 
 extern "C" int64_t eslam_bwd_workspace_bytes(int64_t n_points) {
@@ -587,25 +633,34 @@ static AuxStream* aux_stream() {
     return state == 1 ? &a : nullptr;
 }
 
+// mode 0: free points (g_o in the workspace); 1: rays, upstream gradients in rb; 2: rays, mapping-loss gradients from li
 static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, const Bound& bnd, const float* rays_o,
-                      const float* rays_d, const float* z_or_pts, int64_t R, int S, bool render, const float* feat,
+                      const float* rays_d, const float* z_or_pts, int64_t R, int S, int mode, const float* feat,
                       float* g_o, float* g_feat, float* slabs, const int* perm, float* g_dec, float* g_out_a, float* g_out_b,
-                      const float* beta_parts, int n_beta_parts, float* g_beta, hipStream_t st) {
+                      RayBwdIn rb, const LossGradIn* li, float* g_beta, hipStream_t st) {
+    const bool render = mode != 0;
     const int64_t N = render ? R * S : R;
     PlaneSet ps;
     for (int i = 0; i < NPL; ++i) ps.p[i] = planes[i];
     const bool cl = eslam_planes_channels_last(planes, 0, NPL);
 
-    // decoder MLP backward
-    const int64_t ntiles = (N + 63) / 64;
+    // decoder MLP backward (rays: with the composite backward, and the loss gradient, in the same launch)
+    const int64_t ntiles = render ? R : (N + 63) / 64;                 // a wave's unit of work: a ray, or 64 free points
     const int nwg = (int)((ntiles + 3) / 4 < MLP_BWD_MAX_WG ? (ntiles + 3) / 4 : MLP_BWD_MAX_WG);
+    float* beta_parts = slabs + (int64_t)MLP_BWD_MAX_WG * 4 * 2 * SLAB;
+    rb.beta_parts = render ? beta_parts : nullptr;
+    const LossGradIn none = {};
     eslam_prof_begin(PROF_MLP_BWD, st);
-    if (g_dec)
-        hipLaunchKernelGGL(mlp_bwd_kernel<true>, dim3(nwg, 2), dim3(256), 0, st, *dec, feat, g_o, N, g_feat, slabs);
-    else
-        hipLaunchKernelGGL(mlp_bwd_kernel<false>, dim3(nwg, 2), dim3(256), 0, st, *dec, feat, g_o, N, g_feat, slabs);
+#define LAUNCH_MB(MD, WG) \
+    hipLaunchKernelGGL((mlp_bwd_kernel<MD, WG>), dim3(nwg, 2), dim3(256), 0, st, *dec, feat, g_o, N, g_feat, slabs, rb, \
+                       li ? *li : none)
+    if (mode == 0) { if (g_dec) LAUNCH_MB(0, true); else LAUNCH_MB(0, false); }
+    else if (mode == 1) { if (g_dec) LAUNCH_MB(1, true); else LAUNCH_MB(1, false); }
+    else { if (g_dec) LAUNCH_MB(2, true); else LAUNCH_MB(2, false); }
+#undef LAUNCH_MB
     eslam_prof_end(PROF_MLP_BWD, st);
     if (int rc = eslam_check_launch("mlp_bwd_kernel")) return rc;
+    const int n_beta_parts = render ? nwg : 0;
     AuxStream* aux = nullptr;
     if (g_dec) {
     // The slab reduction (44 workgroups, latency-bound, ~16 us) does not depend on the scatter and the scatter does not
@@ -622,7 +677,7 @@ static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, 
     }
     eslam_prof_begin(PROF_DEC_REDUCE, rs);
     hipLaunchKernelGGL(dec_grad_reduce_kernel, dim3((SLAB + 63) / 64, 2), dim3(1024), 0, rs, slabs, nwg, g_dec,
-                       beta_parts, n_beta_parts, g_beta);
+                       render ? beta_parts : (const float*)nullptr, n_beta_parts, g_beta);
     eslam_prof_end(PROF_DEC_REDUCE, rs);
     if (int rc = eslam_check_launch("dec_grad_reduce_kernel")) return rc;
     if (aux && hipEventRecord(aux->join, rs) != hipSuccess) {
@@ -631,7 +686,7 @@ static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, 
     }
     } else {
         aux = nullptr;
-        if (g_beta) {      // beta's gradient does not go through the decoders: still sum its partials
+        if (g_beta && render) {      // beta's gradient does not go through the decoders: still sum its partials
             hipLaunchKernelGGL(beta_sum_kernel, dim3(1), dim3(1024), 0, st, beta_parts, n_beta_parts, g_beta);
             if (int rc = eslam_check_launch("beta_sum_kernel")) return rc;
         }
@@ -654,7 +709,7 @@ static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, 
     }
     // position gradients
     if (g_out_a) {
-        const int64_t nunits = render ? R : ntiles;
+        const int64_t nunits = render ? R : (N + 63) / 64;
         dim3 grid((unsigned)((nunits + 3) / 4)), block(256);
 #define LAUNCH(CLv, RD)                                                                                            \
     hipLaunchKernelGGL((coord_bwd_kernel<CLv, RD>), grid, block, 0, st, ps, bnd, rays_o, rays_d, z_or_pts, (int)R, \
@@ -675,26 +730,27 @@ static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, 
     return 0;
 }
 
-extern "C" int eslam_render_bwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
-                                const float* rays_o, const float* rays_d, const float* z_vals, int R, int S,
-                                const float* sdf, const float* raw_rgb, const float* feat, const float* g_depth,
-                                const float* g_rgb, const float* g_sdf, float* g_dec, float* g_beta, float* g_rays_o,
-                                float* g_rays_d, const int32_t* ray_order, void* workspace, eslam_stream_t stream) {
+static int render_bwd_impl(const char* who, const eslam_plane_t* planes, const eslam_decoders_t* dec,
+                           const float* bound6_host, const float* rays_o, const float* rays_d, const float* z_vals, int R,
+                           int S, const float* sdf, const float* raw_rgb, const float* feat, const float* g_depth,
+                           const float* g_rgb, const float* g_sdf, const LossGradIn* li, float* g_dec, float* g_beta,
+                           float* g_rays_o, float* g_rays_d, const int32_t* ray_order, void* workspace,
+                           eslam_stream_t stream) {
     if (R <= 0) return 0;
     if (S <= 0 || S > ESLAM_MAX_SAMPLES) {
-        eslam_set_error("eslam_render_bwd: S=%d outside [1,%d]", S, ESLAM_MAX_SAMPLES);
+        eslam_set_error("%s: S=%d outside [1,%d]", who, S, ESLAM_MAX_SAMPLES);
         return 1;
     }
     if (!planes || !dec || !bound6_host || !rays_o || !rays_d || !z_vals || !sdf || !raw_rgb || !feat || !workspace) {
-        eslam_set_error("eslam_render_bwd: null argument");
+        eslam_set_error("%s: null argument", who);
         return 1;
     }
     if ((g_rays_o == nullptr) != (g_rays_d == nullptr)) {
-        eslam_set_error("eslam_render_bwd: g_rays_o and g_rays_d must both be given or both be NULL");
+        eslam_set_error("%s: g_rays_o and g_rays_d must both be given or both be NULL", who);
         return 1;
     }
     if ((int64_t)R * S * 128 >= ((int64_t)1 << 40)) {
-        eslam_set_error("eslam_render_bwd: batch too large");
+        eslam_set_error("%s: batch too large", who);
         return 1;
     }
     if (eslam_validate_planes(planes, 0, NPL)) return 1;
@@ -711,17 +767,41 @@ extern "C" int eslam_render_bwd(const eslam_plane_t* planes, const eslam_decoder
         perm = own;
     }
     const Bound bnd = make_bound(bound6_host);
+    RayBwdIn rb = {};
+    rb.z_vals = z_vals; rb.sdf = sdf; rb.raw_rgb = raw_rgb; rb.beta = dec->beta;
+    rb.g_depth = g_depth; rb.g_rgb = g_rgb; rb.g_sdf = g_sdf; rb.R = R; rb.S = S;
+    return bwd_common(planes, dec, bnd, rays_o, rays_d, z_vals, R, S, li ? 2 : 1, feat, g_o, g_feat, slabs, perm, g_dec,
+                      g_rays_o, g_rays_d, rb, li, g_beta, st);
+}
 
-    // g_beta partials: one float per composite_bwd workgroup, stored behind the decoder-gradient slabs
-    float* beta_parts = slabs + (int64_t)MLP_BWD_MAX_WG * 4 * 2 * SLAB;
-    const int n_beta_parts = (R + 3) / 4;
-    eslam_prof_begin(PROF_COMPOSITE_BWD, st);
-    hipLaunchKernelGGL(composite_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, st, z_vals, sdf, raw_rgb, dec->beta,
-                       g_depth, g_rgb, g_sdf, R, S, g_o, beta_parts);
-    eslam_prof_end(PROF_COMPOSITE_BWD, st);
-    if (int rc = eslam_check_launch("composite_bwd_kernel")) return rc;
-    return bwd_common(planes, dec, bnd, rays_o, rays_d, z_vals, R, S, true, feat, g_o, g_feat, slabs, perm, g_dec,
-                      g_rays_o, g_rays_d, beta_parts, n_beta_parts, g_beta, st);
+extern "C" int eslam_render_bwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
+                                const float* rays_o, const float* rays_d, const float* z_vals, int R, int S,
+                                const float* sdf, const float* raw_rgb, const float* feat, const float* g_depth,
+                                const float* g_rgb, const float* g_sdf, float* g_dec, float* g_beta, float* g_rays_o,
+                                float* g_rays_d, const int32_t* ray_order, void* workspace, eslam_stream_t stream) {
+    return render_bwd_impl("eslam_render_bwd", planes, dec, bound6_host, rays_o, rays_d, z_vals, R, S, sdf, raw_rgb, feat,
+                           g_depth, g_rgb, g_sdf, nullptr, g_dec, g_beta, g_rays_o, g_rays_d, ray_order, workspace, stream);
+}
+
+extern "C" int eslam_render_bwd_loss(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
+                                     const float* rays_o, const float* rays_d, const float* z_vals, int R, int S,
+                                     const float* sdf, const float* raw_rgb, const float* feat, const float* depth,
+                                     const float* rgb, const float* gt_depth, const float* gt_color, double truncation,
+                                     const float* weights5_host, const uint8_t* ray_mask, const float* acc,
+                                     const float* upstream, float* loss_out, const float* g_depth, const float* g_rgb,
+                                     const float* g_sdf, float* g_dec, float* g_beta, float* g_rays_o, float* g_rays_d,
+                                     const int32_t* ray_order, void* workspace, eslam_stream_t stream) {
+    if (!depth || !rgb || !gt_depth || !gt_color || !weights5_host || !acc) {
+        eslam_set_error("eslam_render_bwd_loss: null loss argument");
+        return 1;
+    }
+    LossGradIn li = {};
+    li.gt_depth = gt_depth; li.gt_color = gt_color; li.ray_mask = ray_mask; li.depth = depth; li.rgb = rgb;
+    li.acc = acc; li.upstream = upstream; li.loss_out = loss_out;
+    li.tr = make_trunc(truncation);
+    li.w = LossW{weights5_host[0], weights5_host[1], weights5_host[2], weights5_host[3], weights5_host[4]};
+    return render_bwd_impl("eslam_render_bwd_loss", planes, dec, bound6_host, rays_o, rays_d, z_vals, R, S, sdf, raw_rgb,
+                           feat, g_depth, g_rgb, g_sdf, &li, g_dec, g_beta, g_rays_o, g_rays_d, ray_order, workspace, stream);
 }
 
 extern "C" int eslam_decode_bwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
@@ -745,6 +825,6 @@ extern "C" int eslam_decode_bwd(const eslam_plane_t* planes, const eslam_decoder
     const Bound bnd = make_bound(bound6_host);
     hipLaunchKernelGGL(decode_act_bwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, raw, g_raw, N, g_o);
     if (int rc = eslam_check_launch("decode_act_bwd_kernel")) return rc;
-    return bwd_common(planes, dec, bnd, nullptr, nullptr, pts, N, 64, false, feat, g_o, g_feat, slabs, nullptr, g_dec,
-                      g_pts, nullptr, nullptr, 0, nullptr, st);
+    return bwd_common(planes, dec, bnd, nullptr, nullptr, pts, N, 64, 0, feat, g_o, g_feat, slabs, nullptr, g_dec,
+                      g_pts, nullptr, RayBwdIn{}, nullptr, nullptr, st);
 }

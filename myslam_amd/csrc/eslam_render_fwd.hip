@@ -36,14 +36,18 @@ __global__ __launch_bounds__(256, FWD_WAVES) void render_fwd_kernel(const PlaneS
                                                          float* __restrict__ depth_out, float* __restrict__ rgb_out,
                                                          float* __restrict__ sdf_out, float* __restrict__ raw_rgb_out,
                                                          float* __restrict__ feat_out, const int* __restrict__ perm,
-                                                         const LossIn li) {
+                                                         const LossIn li, uint32_t* __restrict__ rng_bump) {
+    // the samplers drew this iteration's random numbers from (seed, *rng_bump) before this kernel started
+    // (eslam_sample_z_all_rng): advance the step for the next iteration (of a replayed graph)
+    if (rng_bump && blockIdx.x == 0 && threadIdx.x == 0) rng_bump[0] += 1u;
     __shared__ __attribute__((aligned(16))) float wlds[2 * DEC_LDS];
     stage_decoder_weights(wlds, dec, threadIdx.x, blockDim.x);
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int r = lane & 15, q = lane >> 4;
+    const int r = lane & 15, q = lane >> 4;                                  // MFMA role
+    const int gp = gather_point<CL>(lane), gq = gather_piece<CL>(lane);     // gather role
     float lv[A_COUNT];                     // LOSS: this lane's share of the accumulators
 #pragma unroll
     for (int k = 0; k < A_COUNT; ++k) lv[k] = 0.0f;
@@ -80,17 +84,18 @@ __global__ __launch_bounds__(256, FWD_WAVES) void render_fwd_kernel(const PlaneS
 #pragma unroll 1
             for (int b = 0; b < nblk; ++b) {
                 const int oz0 = opaque_zero(b);
-                // block role: normalised coordinates of point 16b + r
-                const int sb = c0 + 16 * b + r;
+                // gather role: normalised coordinates of point 16b + gp
+                const int sb = c0 + 16 * b + gp;
                 const float zb = zrow[min(sb, S - 1)];
                 const float px = norm_coord(ox + dx * zb, bnd.lo[0], bnd.hi[0]);
                 const float py = norm_coord(oy + dy * zb, bnd.lo[1], bnd.hi[1]);
                 const float pz = norm_coord(oz + dz * zb, bnd.lo[2], bnd.hi[2]);
                 float feat[16];
-                gather_features<CL>(planes, d, px, py, pz, q, feat, oz0);
+                gather_features<CL>(planes, d, px, py, pz, gq, feat, oz0);
                 if (SAVE) {
-                    if (sb < S) store_features(feat_out, (int64_t)ray * S + sb, d, q, feat);
+                    if (sb < S) store_features(feat_out, (int64_t)ray * S + sb, d, gq, feat);
                 }
+                to_mfma_role<CL, 16>(feat, lane);
                 // operand fragments are re-read from LDS per block (9 ds_read_b128) instead of being kept live across
                 // the gather, where they would push the kernel past 128 VGPRs
                 DecFrag f;
@@ -179,7 +184,8 @@ __global__ __launch_bounds__(256, FWD_WAVES) void decode_fwd_kernel(const PlaneS
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int r = lane & 15, q = lane >> 4;
+    const int r = lane & 15, q = lane >> 4;                                  // MFMA role
+    const int gp = gather_point<CL>(lane), gq = gather_piece<CL>(lane);     // gather role
     const int64_t ntiles = (N + 63) / 64;
 
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
@@ -193,16 +199,17 @@ __global__ __launch_bounds__(256, FWD_WAVES) void decode_fwd_kernel(const PlaneS
 #pragma unroll 1
             for (int b = 0; b < nblk; ++b) {
                 const int oz0 = opaque_zero(b);
-                const int64_t pb = p0 + 16 * b + r;
+                const int64_t pb = p0 + 16 * b + gp;
                 const int64_t pc = min(pb, N - 1);
                 const float px = norm_coord(pts[pc * 3 + 0], bnd.lo[0], bnd.hi[0]);
                 const float py = norm_coord(pts[pc * 3 + 1], bnd.lo[1], bnd.hi[1]);
                 const float pz = norm_coord(pts[pc * 3 + 2], bnd.lo[2], bnd.hi[2]);
                 float feat[16];
-                gather_features<CL>(planes, d, px, py, pz, q, feat, oz0);
+                gather_features<CL>(planes, d, px, py, pz, gq, feat, oz0);
                 if (SAVE) {
-                    if (pb < N) store_features(feat_out, pb, d, q, feat);
+                    if (pb < N) store_features(feat_out, pb, d, gq, feat);
                 }
+                to_mfma_role<CL, 16>(feat, lane);
                 DecFrag f;
                 load_dec_frag(f, wlds + d * DEC_LDS + oz0, r, q);
                 float4_t h1, h2;
@@ -249,7 +256,7 @@ static Bound make_bound(const float* b6) {
 static int render_fwd_common(const char* who, const eslam_plane_t* planes, const eslam_decoders_t* dec,
                              const float* bound6_host, const float* rays_o, const float* rays_d, const float* z_vals,
                              int R, int S, float* depth, float* rgb, float* sdf, float* raw_rgb, float* feat,
-                             const int32_t* ray_order, const LossIn* li, eslam_stream_t stream) {
+                             const int32_t* ray_order, const LossIn* li, uint32_t* rng_bump, eslam_stream_t stream) {
     if (R <= 0) return 0;
     if (S <= 0 || S > ESLAM_MAX_SAMPLES) {
         eslam_set_error("%s: S=%d outside [1,%d]", who, S, ESLAM_MAX_SAMPLES);
@@ -275,7 +282,7 @@ static int render_fwd_common(const char* who, const eslam_plane_t* planes, const
     const LossIn none = {};
 #define LAUNCH(CLv, SV, LS)                                                                                             \
     hipLaunchKernelGGL((render_fwd_kernel<CLv, SV, LS>), grid, block, 0, st, ps, *dec, bnd, rays_o, rays_d, z_vals, R, \
-                       S, depth, rgb, sdf, raw_rgb, feat, (const int*)ray_order, LS ? *li : none)
+                       S, depth, rgb, sdf, raw_rgb, feat, (const int*)ray_order, LS ? *li : none, rng_bump)
     eslam_prof_begin(PROF_RENDER_FWD, st);
     if (li) {
         if (cl && save) LAUNCH(true, true, true);
@@ -296,9 +303,9 @@ static int render_fwd_common(const char* who, const eslam_plane_t* planes, const
 extern "C" int eslam_render_fwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
                                 const float* rays_o, const float* rays_d, const float* z_vals, int R, int S,
                                 float* depth, float* rgb, float* sdf, float* raw_rgb, float* feat,
-                                const int32_t* ray_order, eslam_stream_t stream) {
+                                const int32_t* ray_order, uint32_t* rng_bump, eslam_stream_t stream) {
     return render_fwd_common("eslam_render_fwd", planes, dec, bound6_host, rays_o, rays_d, z_vals, R, S, depth, rgb, sdf,
-                             raw_rgb, feat, ray_order, nullptr, stream);
+                             raw_rgb, feat, ray_order, nullptr, rng_bump, stream);
 }
 
 extern "C" int eslam_render_fwd_loss(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
@@ -306,7 +313,7 @@ extern "C" int eslam_render_fwd_loss(const eslam_plane_t* planes, const eslam_de
                                      float* depth, float* rgb, float* sdf, float* raw_rgb, float* feat,
                                      const int32_t* ray_order, const float* gt_depth, const float* gt_color,
                                      double truncation, const float* weights5_host, const uint8_t* ray_mask,
-                                     float* scratch, float* acc, float* loss, eslam_stream_t stream) {
+                                     float* scratch, float* acc, float* loss, uint32_t* rng_bump, eslam_stream_t stream) {
     if (!gt_depth || !gt_color || !weights5_host || !scratch || !acc) {
         eslam_set_error("eslam_render_fwd_loss: null loss argument");
         return 1;
@@ -321,7 +328,7 @@ extern "C" int eslam_render_fwd_loss(const eslam_plane_t* planes, const eslam_de
     li.tr = make_trunc(truncation);
     li.w = LossW{weights5_host[0], weights5_host[1], weights5_host[2], weights5_host[3], weights5_host[4]};
     return render_fwd_common("eslam_render_fwd_loss", planes, dec, bound6_host, rays_o, rays_d, z_vals, R, S, depth, rgb,
-                             sdf, raw_rgb, feat, ray_order, &li, stream);
+                             sdf, raw_rgb, feat, ray_order, &li, rng_bump, stream);
 }
 
 extern "C" int eslam_decode_fwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,

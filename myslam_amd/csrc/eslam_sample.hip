@@ -159,6 +159,37 @@ __global__ void prefilter_kernel(const float* __restrict__ rays_o, const float* 
 // One wave per ray.  The two sequences are ascending, so the "sort" of Renderer.py:102 is a rank merge:
 // element position = own index + number of elements of the other sequence in front of it.
 // ---------------------------------------------------------------------------------------------------------
+// Counter-based uniform numbers for the jitter (Renderer.py:59) and the importance draw (common.py:59) when the caller
+// does not inject them: U = hash(seed, step, stream, element) / 2^24 in [0, 1), the grid torch.rand draws from.  step is
+// read from device memory (rng.state) so that a replayed hipGraph draws fresh numbers; the forward kernel that consumes
+// the samples increments it (eslam_render_fwd*, rng_bump) - one launch per iteration less than a torch.rand pool.
+struct RngArg {
+    uint32_t seed_lo, seed_hi;
+    const uint32_t* state;       // [1] step counter on the device, or NULL (step 0)
+    int on;                      // 0: numbers come from the t_rand / t_rand_uni / u arrays
+    int perturb;                 // jitter the samples (Renderer.perturb); the importance draw u is needed either way
+};
+struct Rng { uint32_t k0, k1; bool on, perturb; };
+
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ Rng make_rng(const RngArg a) {
+    Rng r;
+    const uint32_t step = (a.on && a.state) ? a.state[0] : 0u;
+    r.k0 = a.seed_lo ^ (step * 0x9E3779B9u);
+    r.k1 = a.seed_hi + step * 0x7F4A7C15u;
+    r.on = a.on != 0;
+    r.perturb = a.perturb != 0;
+    return r;
+}
+__device__ __forceinline__ float rng_uniform(const Rng& r, uint32_t stream, uint32_t idx) {
+    uint32_t h = mix32(idx * 0x9E3779B1u + r.k0 + stream * 0x85EBCA77u);
+    h = mix32(h + r.k1);
+    return (float)(h >> 8) * 5.9604644775390625e-08f;      // 2^-24
+}
+
 __device__ __forceinline__ float jitter_one(const float* zs, int i, int S, float t) {
     // Renderer.py:55-61
     const float zi = zs[i];
@@ -171,7 +202,7 @@ __device__ __forceinline__ float jitter_one(const float* zs, int i, int S, float
 __device__ __forceinline__ void depth_guided_row(float d, int ray, int n_strat, int n_imp, float c15, float c3,
                                                  const float* __restrict__ t_free, const float* __restrict__ t_surf,
                                                  const float* __restrict__ t_rand, float* __restrict__ z_vals, float* zs,
-                                                 int lane) {
+                                                 int lane, const Rng& rng) {
     const int S = n_strat + n_imp;
     const float d12 = __fmul_rn(1.2f, d);          // Renderer.py:100
     const float dlo = __fsub_rn(d, c15);           // Renderer.py:97
@@ -195,7 +226,8 @@ __device__ __forceinline__ void depth_guided_row(float d, int ray, int n_strat, 
     WAVE_SYNC();
     float* out = z_vals + (int64_t)ray * S;
     for (int i = lane; i < S; i += WAVE)
-        out[i] = t_rand ? jitter_one(zs, i, S, t_rand[(int64_t)ray * S + i]) : zs[i];
+        out[i] = t_rand ? jitter_one(zs, i, S, t_rand[(int64_t)ray * S + i])
+                        : (rng.on && rng.perturb) ? jitter_one(zs, i, S, rng_uniform(rng, 0u, (uint32_t)(ray * S + i))) : zs[i];
 }
 
 __global__ __launch_bounds__(256) void sample_z_kernel(const float* __restrict__ gt_depth, int R, int n_strat,
@@ -209,7 +241,7 @@ __global__ __launch_bounds__(256) void sample_z_kernel(const float* __restrict__
     if (ray >= R) return;
     const float d = gt_depth[ray];
     if (!(d > 0.0f)) return;                       // Renderer.py:92: handled by the importance sampler
-    depth_guided_row(d, ray, n_strat, n_imp, c15, c3, t_free, t_surf, t_rand, z_vals, zs_all[wave], lane);
+    depth_guided_row(d, ray, n_strat, n_imp, c15, c3, t_free, t_surf, t_rand, z_vals, zs_all[wave], lane, Rng{0u, 0u, false, false});
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -227,7 +259,8 @@ __global__ __launch_bounds__(256, 2) void importance_z_kernel(const PlaneSet pla
                                                            const float* __restrict__ u_rand,
                                                            float* __restrict__ z_vals, float c15, float c3,
                                                            const float* __restrict__ t_surf,
-                                                           const float* __restrict__ t_rand) {
+                                                           const float* __restrict__ t_rand, const RngArg rng_arg) {
+    const Rng rng = make_rng(rng_arg);
     __shared__ __attribute__((aligned(16))) float wlds[2 * DEC_LDS];
     __shared__ float zu_all[4][ESLAM_MAX_SAMPLES];      // jittered uniform samples, then the merged list
     __shared__ float wt_all[4][ESLAM_MAX_SAMPLES];      // weights -> cdf
@@ -238,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void importance_z_kernel(const PlaneSet pla
             const float d0 = gt_depth[ray0];
             if (d0 > 0.0f)
                 depth_guided_row(d0, ray0, n_strat, n_imp, c15, c3, t_free, t_surf, t_rand, z_vals,
-                                 zu_all[threadIdx.x >> 6], threadIdx.x & 63);
+                                 zu_all[threadIdx.x >> 6], threadIdx.x & 63, rng);
         }
     }
     {   // most batches have no depth-less ray at all: leave before the 11 KB of weights are staged
@@ -252,7 +285,8 @@ __global__ __launch_bounds__(256, 2) void importance_z_kernel(const PlaneSet pla
     stage_decoder_weights(wlds, dec, threadIdx.x, blockDim.x);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 15, q = lane >> 4;
+    const int r = lane & 15, q = lane >> 4;                                  // MFMA role (eslam_decode_tile.h)
+    const int gp = gather_point<CL>(lane), gq = gather_piece<CL>(lane);     // gather role
     const int ray = blockIdx.x * 4 + wave;
     if (ray >= R) return;
     if (gt_depth[ray] > 0.0f) return;
@@ -271,7 +305,8 @@ __global__ __launch_bounds__(256, 2) void importance_z_kernel(const PlaneSet pla
     }
     WAVE_SYNC();
     for (int i = lane; i < n_strat; i += WAVE)
-        zu[i] = t_rand_uni ? jitter_one(wt, i, n_strat, t_rand_uni[(int64_t)ray * n_strat + i]) : wt[i];
+        zu[i] = t_rand_uni ? jitter_one(wt, i, n_strat, t_rand_uni[(int64_t)ray * n_strat + i])
+                           : (rng.on && rng.perturb) ? jitter_one(wt, i, n_strat, rng_uniform(rng, 1u, (uint32_t)(ray * n_strat + i))) : wt[i];
     WAVE_SYNC();
 
     // SDF decode of the n_strat points (geometry planes only), alpha, transmittance, weights (Renderer.py:122-129)
@@ -284,13 +319,14 @@ __global__ __launch_bounds__(256, 2) void importance_z_kernel(const PlaneSet pla
         for (int b = 0; b < nblk; ++b) {
             {
                 const int oz0 = opaque_zero(b);
-                const float z = zu[min(c0 + 16 * b + r, n_strat - 1)];
+                const float z = zu[min(c0 + 16 * b + gp, n_strat - 1)];
                 // Renderer.py:122: o + d*z (mul then add, as torch does)
                 const float x = norm_coord(__fadd_rn(o[0], __fmul_rn(d[0], z)), bnd.lo[0], bnd.hi[0]);
                 const float y = norm_coord(__fadd_rn(o[1], __fmul_rn(d[1], z)), bnd.lo[1], bnd.hi[1]);
                 const float zz = norm_coord(__fadd_rn(o[2], __fmul_rn(d[2], z)), bnd.lo[2], bnd.hi[2]);
                 float feat[16];
-                gather_features<CL>(planes, 0, x, y, zz, q, feat, oz0);
+                gather_features<CL>(planes, 0, x, y, zz, gq, feat, oz0);
+                to_mfma_role<CL, 16>(feat, lane);
                 DecFrag f;
                 load_dec_frag(f, wlds + oz0, r, q);
                 float4_t h1, h2;
@@ -326,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void importance_z_kernel(const PlaneSet pla
     }
     WAVE_SYNC();
     for (int i = lane; i < n_imp; i += WAVE) {
-        const float u = u_rand[(int64_t)ray * n_imp + i];
+        const float u = u_rand ? u_rand[(int64_t)ray * n_imp + i] : rng_uniform(rng, 2u, (uint32_t)(ray * n_imp + i));
         int inds = 0;                       // searchsorted(cdf, u, right=True): #entries <= u
         for (int k = 0; k < nb; ++k) inds += (wt[k] <= u) ? 1 : 0;
         const int below = max(inds - 1, 0);
@@ -483,28 +519,32 @@ extern "C" int eslam_importance_z(const eslam_plane_t* planes, const eslam_decod
     if (eslam_planes_channels_last(planes, 0, 6))
         hipLaunchKernelGGL((importance_z_kernel<true, false>), grid, block, 0, (hipStream_t)stream, ps, *dec, bnd, rays_o,
                            rays_d, gt_depth, R, n_strat, n_imp, t_free, t_rand_uni, u, z_vals, 0.0f, 0.0f,
-                           (const float*)nullptr, (const float*)nullptr);
+                           (const float*)nullptr, (const float*)nullptr, RngArg{});
     else
         hipLaunchKernelGGL((importance_z_kernel<false, false>), grid, block, 0, (hipStream_t)stream, ps, *dec, bnd, rays_o,
                            rays_d, gt_depth, R, n_strat, n_imp, t_free, t_rand_uni, u, z_vals, 0.0f, 0.0f,
-                           (const float*)nullptr, (const float*)nullptr);
+                           (const float*)nullptr, (const float*)nullptr, RngArg{});
     eslam_prof_end(PROF_IMPORTANCE_Z, (hipStream_t)stream);
     return eslam_check_launch("importance_z_kernel");
 }
 
-extern "C" int eslam_sample_z_all(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
-                                  const float* rays_o, const float* rays_d, const float* gt_depth, int R, int n_strat,
-                                  int n_imp, double truncation, const float* t_free, const float* t_surf,
-                                  const float* t_rand, const float* t_rand_uni, const float* u, float* z_vals,
-                                  eslam_stream_t stream) {
+static int sample_z_all_impl(const char* who, const eslam_plane_t* planes, const eslam_decoders_t* dec,
+                             const float* bound6_host, const float* rays_o, const float* rays_d, const float* gt_depth,
+                             int R, int n_strat, int n_imp, double truncation, const float* t_free, const float* t_surf,
+                             const float* t_rand, const float* t_rand_uni, const float* u, const RngArg rng,
+                             float* z_vals, eslam_stream_t stream) {
     if (R <= 0) return 0;
     if (n_strat < 3 || n_imp < 0 || n_strat + n_imp > ESLAM_MAX_SAMPLES) {
-        eslam_set_error("eslam_sample_z_all: n_strat=%d n_imp=%d unsupported", n_strat, n_imp);
+        eslam_set_error("%s: n_strat=%d n_imp=%d unsupported", who, n_strat, n_imp);
         return 1;
     }
-    if (!planes || !dec || !bound6_host || !rays_o || !rays_d || !gt_depth || !t_free || (n_imp > 0 && (!u || !t_surf)) ||
-        !z_vals) {
-        eslam_set_error("eslam_sample_z_all: null argument");
+    if (!planes || !dec || !bound6_host || !rays_o || !rays_d || !gt_depth || !t_free ||
+        (n_imp > 0 && ((!u && !rng.on) || !t_surf)) || !z_vals) {
+        eslam_set_error("%s: null argument", who);
+        return 1;
+    }
+    if ((int64_t)R * (n_strat + n_imp) >= ((int64_t)1 << 32)) {
+        eslam_set_error("%s: batch too large", who);
         return 1;
     }
     if (eslam_validate_planes(planes, 0, 6)) return 1;
@@ -517,10 +557,30 @@ extern "C" int eslam_sample_z_all(const eslam_plane_t* planes, const eslam_decod
     eslam_prof_begin(PROF_SAMPLE_Z, (hipStream_t)stream);
     if (eslam_planes_channels_last(planes, 0, 6))
         hipLaunchKernelGGL((importance_z_kernel<true, true>), grid, block, 0, (hipStream_t)stream, ps, *dec, bnd, rays_o,
-                           rays_d, gt_depth, R, n_strat, n_imp, t_free, t_rand_uni, u, z_vals, c15, c3, t_surf, t_rand);
+                           rays_d, gt_depth, R, n_strat, n_imp, t_free, t_rand_uni, u, z_vals, c15, c3, t_surf, t_rand, rng);
     else
         hipLaunchKernelGGL((importance_z_kernel<false, true>), grid, block, 0, (hipStream_t)stream, ps, *dec, bnd, rays_o,
-                           rays_d, gt_depth, R, n_strat, n_imp, t_free, t_rand_uni, u, z_vals, c15, c3, t_surf, t_rand);
+                           rays_d, gt_depth, R, n_strat, n_imp, t_free, t_rand_uni, u, z_vals, c15, c3, t_surf, t_rand, rng);
     eslam_prof_end(PROF_SAMPLE_Z, (hipStream_t)stream);
     return eslam_check_launch("importance_z_kernel<with depth>");
+}
+
+extern "C" int eslam_sample_z_all(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
+                                  const float* rays_o, const float* rays_d, const float* gt_depth, int R, int n_strat,
+                                  int n_imp, double truncation, const float* t_free, const float* t_surf,
+                                  const float* t_rand, const float* t_rand_uni, const float* u, float* z_vals,
+                                  eslam_stream_t stream) {
+    return sample_z_all_impl("eslam_sample_z_all", planes, dec, bound6_host, rays_o, rays_d, gt_depth, R, n_strat, n_imp,
+                             truncation, t_free, t_surf, t_rand, t_rand_uni, u, RngArg{}, z_vals, stream);
+}
+
+extern "C" int eslam_sample_z_all_rng(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
+                                      const float* rays_o, const float* rays_d, const float* gt_depth, int R, int n_strat,
+                                      int n_imp, double truncation, const float* t_free, const float* t_surf, int perturb,
+                                      uint64_t seed, const uint32_t* rng_state, float* z_vals, eslam_stream_t stream) {
+    RngArg rng;
+    rng.seed_lo = (uint32_t)seed; rng.seed_hi = (uint32_t)(seed >> 32); rng.state = rng_state; rng.on = 1;
+    rng.perturb = perturb ? 1 : 0;
+    return sample_z_all_impl("eslam_sample_z_all_rng", planes, dec, bound6_host, rays_o, rays_d, gt_depth, R, n_strat, n_imp,
+                             truncation, t_free, t_surf, nullptr, nullptr, nullptr, rng, z_vals, stream);
 }

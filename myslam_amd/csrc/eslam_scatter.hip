@@ -51,10 +51,15 @@ __device__ __forceinline__ unsigned spread3(unsigned v) {      // 10 bits -> eve
 #define ORD_BITS 5
 #define ORD_CELLS (1 << (3 * ORD_BITS))      // 32768 words = 65536 packed 16-bit counters = 128 KB of LDS
 #define ORD_PER_THREAD (SORT_MAX / 1024)
+// key_bits (12, 14 or 16): keys of the counting sort.  The histogram's zero fill and scan are what this single-workgroup
+// kernel spends its time on, so small batches get short keys (12 bits for <= 1024 rays: 2048 words instead of 32768).
 __global__ __launch_bounds__(1024) void ray_order_kernel(const float* __restrict__ rays_o,
                                                          const float* __restrict__ rays_d, int R,
-                                                         int* __restrict__ perm) {
-    extern __shared__ __attribute__((aligned(16))) unsigned hist[];       // [ORD_CELLS]
+                                                         int* __restrict__ perm, int key_bits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned hist[];       // [(1 << key_bits) / 2] packed 16-bit counters
+    const int nwords = (1 << key_bits) >> 1;
+    const int hbits = key_bits >> 1;                                      // Hilbert grid: 2^hbits x 2^hbits
+    const int mbits = key_bits / 3;                                       // Morton grid: 2^mbits per axis
     __shared__ float red[16][6];
     __shared__ float red2[16][13];
     __shared__ unsigned wsum[16];
@@ -98,7 +103,7 @@ __global__ __launch_bounds__(1024) void ray_order_kernel(const float* __restrict
             red2[wave][a] = olo[a]; red2[wave][3 + a] = ohi[a]; red2[wave][6 + a] = dsum[a];
         }
     }
-    for (int i = tid; i < ORD_CELLS; i += 1024) hist[i] = 0u;
+    for (int i = tid; i < nwords; i += 1024) hist[i] = 0u;
     __syncthreads();
     // one origin?  then order by the Hilbert index of the direction in a 2-D chart about the mean direction
     float mdir[3];
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(1024) void ray_order_kernel(const float* __restrict
             float l = red2[0][9 + a], h = red2[0][11 + a];
             for (int w = 1; w < 16; ++w) { l = fminf(l, red2[w][9 + a]); h = fmaxf(h, red2[w][11 + a]); }
             blo[a] = l;
-            sc2[a] = 256.0f / fmaxf(h - l, 1e-6f);
+            sc2[a] = (float)(1 << hbits) / fmaxf(h - l, 1e-6f);
         }
 #pragma unroll
         for (int k = 0; k < ORD_PER_THREAD; ++k) {
@@ -163,15 +168,15 @@ __global__ __launch_bounds__(1024) void ray_order_kernel(const float* __restrict
             if (i < n) {
                 float u, v;
                 chart(base + i, u, v);
-                unsigned x = min((unsigned)fmaxf((u - blo[0]) * sc2[0], 0.f), 255u);
-                unsigned y = min((unsigned)fmaxf((v - blo[1]) * sc2[1], 0.f), 255u);
-                unsigned d = 0;                          // Hilbert index of (x, y) on the 256 x 256 grid
-#pragma unroll
-                for (unsigned sft = 128; sft > 0; sft >>= 1) {
+                const unsigned hmax = (1u << hbits) - 1u;
+                unsigned x = min((unsigned)fmaxf((u - blo[0]) * sc2[0], 0.f), hmax);
+                unsigned y = min((unsigned)fmaxf((v - blo[1]) * sc2[1], 0.f), hmax);
+                unsigned d = 0;                          // Hilbert index of (x, y) on the 2^hbits x 2^hbits grid
+                for (unsigned sft = 1u << (hbits - 1); sft > 0; sft >>= 1) {
                     const unsigned rx = (x & sft) ? 1u : 0u, ry = (y & sft) ? 1u : 0u;
                     d += sft * sft * ((3u * rx) ^ ry);
                     if (ry == 0) {
-                        if (rx == 1) { x = 255u - x; y = 255u - y; }
+                        if (rx == 1) { x = hmax - x; y = hmax - y; }
                         const unsigned tswap = x; x = y; y = tswap;
                     }
                 }
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(1024) void ray_order_kernel(const float* __restrict
             float l = red[0][a], h = red[0][3 + a];
             for (int w = 1; w < 16; ++w) { l = fminf(l, red[w][a]); h = fmaxf(h, red[w][3 + a]); }
             lo[a] = l;
-            scale[a] = (float)(1 << ORD_BITS) / fmaxf(h - l, 1e-6f);
+            scale[a] = (float)(1 << mbits) / fmaxf(h - l, 1e-6f);
         }
 #pragma unroll
         for (int k = 0; k < ORD_PER_THREAD; ++k) {
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(1024) void ray_order_kernel(const float* __restrict
             if (i < n) {
                 float o[3], d[3];
                 unit_dir(base + i, o, d);
-                const unsigned qmax = (1u << ORD_BITS) - 1;
+                const unsigned qmax = (1u << mbits) - 1;
                 const unsigned qx = min((unsigned)fmaxf((o[0] + d[0] - lo[0]) * scale[0], 0.f), qmax);
                 const unsigned qy = min((unsigned)fmaxf((o[1] + d[1] - lo[1]) * scale[1], 0.f), qmax);
                 const unsigned qz = min((unsigned)fmaxf((o[2] + d[2] - lo[2]) * scale[2], 0.f), qmax);
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(1024) void ray_order_kernel(const float* __restrict
     __syncthreads();
     // exclusive scan of the counters (two 16-bit counters per word, at most SORT_MAX = 8192 rays: no overflow):
     // thread t owns words [32t, 32t+32)
-    const int per = ORD_CELLS / 1024;
+    const int per = nwords / 1024;                     // >= 2 (key_bits >= 12)
     unsigned local = 0;
     for (int j = 0; j < per; ++j) {
         const unsigned w = hist[tid * per + j];
@@ -733,8 +738,10 @@ extern "C" int eslam_ray_order(const float* rays_o, const float* rays_d, int R, 
     hipStream_t st = (hipStream_t)stream;
     if (int rc = eslam_scatter_v2_init()) return rc;
     const int chunks = (R + SORT_MAX - 1) / SORT_MAX;
-    hipLaunchKernelGGL(ray_order_kernel, dim3(chunks), dim3(1024), ORD_CELLS * sizeof(unsigned), st, rays_o, rays_d, R,
-                       perm);
+    const int n = R < SORT_MAX ? R : SORT_MAX;         // rays per chunk
+    const int key_bits = n <= 1024 ? 12 : n <= 4096 ? 14 : 16;
+    hipLaunchKernelGGL(ray_order_kernel, dim3(chunks), dim3(1024), ((size_t)1 << key_bits) / 2 * sizeof(unsigned), st, rays_o,
+                       rays_d, R, perm, key_bits);
     return eslam_check_launch("ray_order_kernel");
 }
 

@@ -21,9 +21,11 @@ _SEPARATE_LOSS = os.environ.get("ESLAM_SEPARATE_LOSS", "0") == "1"
 
 class Workload:
     def __init__(self, scene_name, R, n_strat, n_imp, device, zero_frac=0.0, seed=0, channels_last=True,
-                 rays_grad=False, planes="normal", model_seed=0):
+                 rays_grad=False, planes="normal", model_seed=0, shard=None):
         """seed: image / pixel choice of this rank's rays; model_seed: planes and decoders (same on every rank of a
-        data-parallel job, whose replicas must be identical)."""
+        data-parallel job, whose replicas must be identical).  shard = (rank, world): build the WHOLE batch (give every
+        rank the same seed) and keep this rank's contiguous slice of its rays (parallel.shard_slice) - the ray-sharded
+        mapping iteration of SURVEY.md section 8(e); R_total is the batch's ray count."""
         dev = torch.device(device)
         self.device = dev
         sc = scn.make_scene(scene_name)
@@ -54,10 +56,16 @@ class Workload:
             ro, rd, gd, gc = get_samples_at(idx, 0, sc.H, 0, sc.W, R, sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, c2ws,
                                             depth_img, color_img)
             inside = ops.aabb_exit(ro, rd, ops.bound_to_host(sc.bound)) >= gd           # Mapper.py:322-332
-        self.rays_o = ro[inside].contiguous().requires_grad_(rays_grad)
-        self.rays_d = rd[inside].contiguous().requires_grad_(rays_grad)
-        self.gt_depth = gd[inside].contiguous()
-        self.gt_color = gc[inside].contiguous()
+        ro, rd, gd, gc = ro[inside], rd[inside], gd[inside], gc[inside]
+        self.R_total = int(ro.shape[0])
+        if shard is not None:
+            from .parallel import shard_slice
+            lo, hi = shard_slice(self.R_total, shard[0], shard[1])
+            ro, rd, gd, gc = ro[lo:hi], rd[lo:hi], gd[lo:hi], gc[lo:hi]
+        self.rays_o = ro.contiguous().requires_grad_(rays_grad)
+        self.rays_d = rd.contiguous().requires_grad_(rays_grad)
+        self.gt_depth = gd.contiguous()
+        self.gt_color = gc.contiguous()
         self.R = int(self.rays_o.shape[0])
         self._one = torch.ones((), device=dev)
         # fixed random numbers / cotangents for the reproducible (test) paths

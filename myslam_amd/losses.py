@@ -17,13 +17,12 @@ def mapping_loss(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weig
     """Mapper.py:337-346: SDF + depth terms over rays with gt_depth > 0, colour over all rays.
     ray_mask (bool [R], optional): restrict every term to these rays - the AABB pre-filter of Mapper.py:322-332 kept
     as a mask, so the batch keeps a static shape and no boolean index forces a host sync.
-    precomputed: the ops.fused_loss context the forward pass ran under (Renderer.render_batch_ray_with_loss): sums and
-    value come from the forward kernel, only the backward is left to do here."""
+    precomputed: the ops.fused_loss context the forward pass ran under (Renderer.render_batch_ray_with_loss): the value
+    comes from the forward kernel and the gradients are formed inside the backward kernel - nothing is launched here."""
     if precomputed is not None:
-        if precomputed.acc is None:
+        if precomputed.loss is None:
             raise RuntimeError("mapping_loss: the fused_loss context has not seen a forward pass")
-        return ops.MappingLossFn.apply(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights,
-                                       precomputed.ray_mask, None, (precomputed.acc, precomputed.value))
+        return precomputed.loss              # an output of the render's own autograd node (ops.RenderFn)
     return ops.MappingLossFn.apply(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights, ray_mask, None,
                                    None)
 

@@ -153,15 +153,37 @@ _FWD_USES_ORDER = os.environ.get("ESLAM_FWD_ORDER", "0") == "1"
 _fused_loss = None
 
 
-class fused_loss:
-    """Context manager: the next RenderFn.forward also forms the sums of the callers' loss in the forward kernel's
-    epilogue (eslam_render_fwd_loss) - one launch less than eslam_loss_value.  After the call `.acc` [16] and `.value` [1]
-    are set; hand them to losses.mapping_loss(..., precomputed=ctx) so that it skips its own reduction.
-    Mapping-style loss only (the tracker's outlier mask depends on the rendered depth itself)."""
+class _LossState:
+    __slots__ = ("truncation", "weights5", "rewrite_value", "gt_depth", "gt_color", "ray_mask", "acc", "value", "acc_global")
 
-    def __init__(self, gt_depth, gt_color, truncation, weights5, ray_mask=None):
+    def __init__(self, truncation, weights5, rewrite_value):
+        self.truncation, self.weights5, self.rewrite_value = float(truncation), tuple(float(v) for v in weights5), rewrite_value
+        self.gt_depth = self.gt_color = self.ray_mask = self.acc = self.value = self.acc_global = None
+
+
+class fused_loss:
+    """Context manager: the next Renderer.render_batch_ray renders WITH the callers' loss: the forward kernel forms the
+    loss's sums in its epilogue (eslam_render_fwd_loss) and the backward kernel forms the loss's gradients itself
+    (eslam_render_bwd_loss) - no loss launches at all, and depth / rgb / sdf gradients never touch memory.
+    After the call `.acc` [16], `.value` [1] and `.loss` (a 0-d tensor connected to the autograd graph: call
+    .backward() on it, or pass the context as losses.mapping_loss(..., precomputed=ctx), which returns it) are set.
+    A ray-sharded caller all-reduces `.acc` in place before the backward; the backward then also rewrites `.value` with
+    the global loss.  Mapping-style loss only (the tracker's outlier mask depends on the rendered depth itself)."""
+
+    def __init__(self, gt_depth, gt_color, truncation, weights5, ray_mask=None, rewrite_value=False):
         self.gt_depth, self.gt_color, self.truncation, self.weights5, self.ray_mask = gt_depth, gt_color, truncation, weights5, ray_mask
-        self.acc = self.value = None
+        self.acc = self.value = self.loss = None
+        # what the backward needs, in an object of its own: the autograd node keeps THIS alive, not the context, which
+        # holds .loss and would otherwise close a reference cycle around the saved activations (134 MB at 4096 x 64)
+        self.state = _LossState(truncation, weights5, rewrite_value)
+
+    @property
+    def acc_global(self):
+        return self.state.acc_global
+
+    @acc_global.setter
+    def acc_global(self, t):
+        self.state.acc_global = t
 
     def __enter__(self):
         global _fused_loss
@@ -173,6 +195,10 @@ class fused_loss:
         _fused_loss = self._prev
 
 
+def current_fused_loss():
+    return _fused_loss
+
+
 def join_ray_order(device):
     """Make the current stream wait for the ray-ordering side stream.  RenderFn joins it in its backward; a caller that
     captures forward and backward into SEPARATE hipGraphs must join inside the forward's capture (parallel.py)."""
@@ -181,14 +207,37 @@ def join_ray_order(device):
         torch.cuda.current_stream(device).wait_stream(side)
 
 
+# In-kernel random numbers of the samplers (eslam_sample_z_all_rng): a step counter per device, read by the sampler and
+# advanced by the forward kernel that consumes its samples.  ESLAM_TORCH_RAND=1 restores the torch.rand pool.
+_USE_KERNEL_RNG = os.environ.get("ESLAM_TORCH_RAND", "0") != "1"
+_rng_pending = {}
+
+
+def _rng_state(dev):
+    return _cached(("rng_state", dev.index), lambda: torch.zeros(4, dtype=torch.int32, device=dev))
+
+
+def _take_rng_bump(dev):
+    """Pointer for the forward kernel's rng_bump if the samples it renders came from the in-kernel generator."""
+    if _rng_pending.pop(dev.index, False):
+        return _hip.ptr(_rng_state(dev))
+    return None
+
+
 class RenderFn(torch.autograd.Function):
-    """depth, rgb, sdf = RenderFn.apply(rays_o, rays_d, z_vals, bound6, beta, order, *12 planes, *12 decoder params)
+    """depth, rgb, sdf[, loss] = RenderFn.apply(rays_o, rays_d, z_vals, bound6, beta, order, lossctx, *12 planes,
+                                                *12 decoder params)
 
     Forward = eslam_render_fwd, backward = eslam_render_bwd (reference: Renderer.py:136-147 and its autograd).
-    order = (perm, stream) from ray_order_async, or None."""
+    order = (perm, stream) from ray_order_async, or None.
+    lossctx = an ops.fused_loss context or None.  With it the forward is eslam_render_fwd_loss, a fourth output `loss`
+    (0-d) is returned, and the gradient arriving on it is turned into the rendered outputs' gradients inside the backward
+    kernel (eslam_render_bwd_loss); gradients arriving on depth / rgb / sdf themselves are added as usual."""
+
+    N_LEAD = 7           # inputs before the planes
 
     @staticmethod
-    def forward(ctx, rays_o, rays_d, z_vals, bound6, beta, order_in, *tensors):
+    def forward(ctx, rays_o, rays_d, z_vals, bound6, beta, order_in, lossctx, *tensors):
         planes, params = tensors[:12], tensors[12:24]
         for n, t in (("rays_o", rays_o), ("rays_d", rays_d), ("z_vals", z_vals)):
             _hip.require_gpu_f32(n, t)
@@ -212,13 +261,15 @@ class RenderFn(torch.autograd.Function):
                 side = None
             # otherwise only the backward needs the order: the ordering kernel (side stream) is joined there, and the
             # forward kernel starts as soon as the samplers are done
-        fl = _fused_loss
+        fl = lossctx
+        ctx.set_materialize_grads(False)
+        ctx.lossctx = None
         with _hip.on_device(dev):
             if fl is None:
                 _hip.check(lib.eslam_render_fwd(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(rays_o),
                                                 _hip.ptr(rays_d), _hip.ptr(z_vals), R, S, _hip.ptr(depth), _hip.ptr(rgb),
                                                 _hip.ptr(sdf), _hip.ptr(raw_rgb), _hip.ptr(feat),
-                                                _hip.ptr(order) if _FWD_USES_ORDER else None,
+                                                _hip.ptr(order) if _FWD_USES_ORDER else None, _take_rng_bump(dev),
                                                 _hip.stream_handle(dev)), "eslam_render_fwd")
             else:
                 _hip.require_gpu_f32("gt_depth", fl.gt_depth)
@@ -226,30 +277,34 @@ class RenderFn(torch.autograd.Function):
                 mask = fl.ray_mask
                 if mask is not None:
                     mask = _c(mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8))
-                fl.acc, fl.value = torch.empty(16, device=dev), torch.empty(1, device=dev)
-                w5 = (ctypes.c_float * 5)(*[float(v) for v in fl.weights5])
+                fl.acc, fl.value = torch.empty(16, device=dev), torch.empty((), device=dev)
+                st = fl.state
+                st.gt_depth, st.gt_color, st.ray_mask, st.acc, st.value = _c(fl.gt_depth), _c(fl.gt_color), mask, fl.acc, fl.value
+                w5 = (ctypes.c_float * 5)(*st.weights5)
                 _hip.check(lib.eslam_render_fwd_loss(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(rays_o),
                                                      _hip.ptr(rays_d), _hip.ptr(z_vals), R, S, _hip.ptr(depth),
                                                      _hip.ptr(rgb), _hip.ptr(sdf), _hip.ptr(raw_rgb), _hip.ptr(feat),
                                                      _hip.ptr(order) if _FWD_USES_ORDER else None,
-                                                     _hip.ptr(_c(fl.gt_depth)), _hip.ptr(_c(fl.gt_color)),
-                                                     float(fl.truncation), w5, _hip.ptr(mask),
+                                                     _hip.ptr(st.gt_depth), _hip.ptr(st.gt_color),
+                                                     st.truncation, w5, _hip.ptr(mask),
                                                      _hip.ptr(_loss_scratch(dev)), _hip.ptr(fl.acc), _hip.ptr(fl.value),
-                                                     _hip.stream_handle(dev)), "eslam_render_fwd_loss")
-                fl.ray_mask_u8 = mask
+                                                     _take_rng_bump(dev), _hip.stream_handle(dev)), "eslam_render_fwd_loss")
+                ctx.lossctx = st
         if needs:
             ctx.bound6 = bound6
             ctx.order_stream = side if order_in is not None else None
-            ctx.save_for_backward(rays_o, rays_d, z_vals, sdf, raw_rgb, feat, order, beta, *planes, *params)
+            ctx.save_for_backward(rays_o, rays_d, z_vals, sdf, raw_rgb, feat, order, beta, depth, rgb, *planes, *params)
         elif order_in is not None and not _FWD_USES_ORDER:
             torch.cuda.current_stream(dev).wait_stream(side)      # nobody will join it later
+        if fl is not None:
+            return depth, rgb, sdf, fl.value.detach()     # an alias: the state must not hold the output object itself
         return depth, rgb, sdf
 
     @staticmethod
-    def backward(ctx, g_depth, g_rgb, g_sdf):
+    def backward(ctx, g_depth, g_rgb, g_sdf, g_loss=None):
         saved = ctx.saved_tensors
-        rays_o, rays_d, z_vals, sdf, raw_rgb, feat, order, beta = saved[:8]
-        planes, params = saved[8:20], saved[20:32]
+        rays_o, rays_d, z_vals, sdf, raw_rgb, feat, order, beta, depth, rgb = saved[:10]
+        planes, params = saved[10:22], saved[22:34]
         R, S = z_vals.shape
         dev = rays_o.device
         lib = _hip.lib()
@@ -257,7 +312,8 @@ class RenderFn(torch.autograd.Function):
             torch.cuda.current_stream(dev).wait_stream(ctx.order_stream)      # join the ordering kernel
             ctx.order_stream = None
         need = ctx.needs_input_grad
-        need_planes = any(need[6:18])
+        L = RenderFn.N_LEAD
+        need_planes = any(need[L:L + 12])
         need_rays = need[0] or need[1]
         grads = None
         sink = _grad_sink
@@ -275,27 +331,41 @@ class RenderFn(torch.autograd.Function):
             g_beta = sink.flat[sink.offsets[24]:sink.offsets[24] + 1] if len(sink.views) > 24 else \
                 torch.empty(1, device=dev)
         else:
-            need_dec = any(need[18:30])
+            need_dec = any(need[L + 12:L + 24])
             g_dec = torch.empty(_hip.N_DEC_PARAMS, device=dev) if need_dec else None
             g_beta = torch.empty(1, device=dev) if need[4] else None
         g_ro = torch.empty(R, 3, device=dev) if need_rays else None
         g_rd = torch.empty(R, 3, device=dev) if need_rays else None
         ws = torch.empty(lib.eslam_bwd_workspace_bytes(R * S), dtype=torch.uint8, device=dev)
         g_depth, g_rgb, g_sdf = _c(g_depth), _c(g_rgb), _c(g_sdf)
+        fl = ctx.lossctx                 # a _LossState
         with _hip.on_device(dev):
-            _hip.check(lib.eslam_render_bwd(arr, ctypes.byref(dec), _hip.make_bound(ctx.bound6), _hip.ptr(rays_o),
-                                            _hip.ptr(rays_d), _hip.ptr(z_vals), R, S, _hip.ptr(sdf), _hip.ptr(raw_rgb),
-                                            _hip.ptr(feat), _hip.ptr(g_depth), _hip.ptr(g_rgb), _hip.ptr(g_sdf),
-                                            _hip.ptr(g_dec), _hip.ptr(g_beta), _hip.ptr(g_ro), _hip.ptr(g_rd),
-                                            _hip.ptr(order), _hip.ptr(ws), _hip.stream_handle(dev)),
-                       "eslam_render_bwd")
+            if fl is not None and g_loss is not None:
+                # the loss's gradients are formed inside the backward kernel from the set sizes in acc (a ray-sharded caller
+                # has put the global ones into acc_global by now)
+                up = _c(g_loss.detach().reshape(1).to(torch.float32))
+                w5 = (ctypes.c_float * 5)(*fl.weights5)
+                _hip.check(lib.eslam_render_bwd_loss(
+                    arr, ctypes.byref(dec), _hip.make_bound(ctx.bound6), _hip.ptr(rays_o), _hip.ptr(rays_d),
+                    _hip.ptr(z_vals), R, S, _hip.ptr(sdf), _hip.ptr(raw_rgb), _hip.ptr(feat), _hip.ptr(depth), _hip.ptr(rgb),
+                    _hip.ptr(fl.gt_depth), _hip.ptr(fl.gt_color), fl.truncation, w5, _hip.ptr(fl.ray_mask),
+                    _hip.ptr(fl.acc if fl.acc_global is None else fl.acc_global), _hip.ptr(up), _hip.ptr(fl.value) if fl.rewrite_value else None, _hip.ptr(g_depth),
+                    _hip.ptr(g_rgb), _hip.ptr(g_sdf), _hip.ptr(g_dec), _hip.ptr(g_beta), _hip.ptr(g_ro), _hip.ptr(g_rd),
+                    _hip.ptr(order), _hip.ptr(ws), _hip.stream_handle(dev)), "eslam_render_bwd_loss")
+            else:
+                _hip.check(lib.eslam_render_bwd(arr, ctypes.byref(dec), _hip.make_bound(ctx.bound6), _hip.ptr(rays_o),
+                                                _hip.ptr(rays_d), _hip.ptr(z_vals), R, S, _hip.ptr(sdf), _hip.ptr(raw_rgb),
+                                                _hip.ptr(feat), _hip.ptr(g_depth), _hip.ptr(g_rgb), _hip.ptr(g_sdf),
+                                                _hip.ptr(g_dec), _hip.ptr(g_beta), _hip.ptr(g_ro), _hip.ptr(g_rd),
+                                                _hip.ptr(order), _hip.ptr(ws), _hip.stream_handle(dev)),
+                           "eslam_render_bwd")
         if sink is not None:
             # the data-parallel caller owns .grad assignment (FlatGrads.assign): hand autograd nothing to accumulate
-            return (g_ro if need[0] else None, g_rd if need[1] else None) + (None,) * 28
+            return (g_ro if need[0] else None, g_rd if need[1] else None) + (None,) * (L - 2 + 24)
         dec_grads = _split_dec_grads(g_dec) if g_dec is not None else [None] * 12
-        out = [g_ro if need[0] else None, g_rd if need[1] else None, None, None, g_beta if need[4] else None, None]
-        out += [grads[i] if (need_planes and need[6 + i]) else None for i in range(12)]
-        out += [dec_grads[i] if need[18 + i] else None for i in range(12)]
+        out = [g_ro if need[0] else None, g_rd if need[1] else None, None, None, g_beta if need[4] else None, None, None]
+        out += [grads[i] if (need_planes and need[L + i]) else None for i in range(12)]
+        out += [dec_grads[i] if need[L + 12 + i] else None for i in range(12)]
         return tuple(out)
 
 
@@ -516,6 +586,25 @@ def sample_z(rays_o, rays_d, gt_depth, all_planes, decoders, bound6, truncation,
     R = gd.shape[0]
     S = n_strat + n_imp
     lib = _hip.lib()
+    if rand is None and _USE_KERNEL_RNG and n_strat >= 3:
+        # the uniform numbers are drawn inside the sampler kernel, keyed on torch's seed and a device step counter
+        z = torch.empty(R, S, device=dev)
+        t_free, t_surf = linspace01(n_strat, dev), linspace01(n_imp, dev)
+        state = _rng_state(dev)
+        if _rng_pending.get(dev.index, False):
+            state[0] += 1              # the previous samples were never rendered: advance the step here
+        ro, rd = _c(rays_o.detach()), _c(rays_d.detach())
+        arr, _ = _hip.make_planes(tuple([p.detach() for p in grp] for grp in all_planes))
+        dec, keep = _hip.make_decoders([p.detach() for p in decoder_params(decoders)],
+                                       beta_tensor(decoders.beta, dev).detach())
+        with _hip.on_device(dev):
+            _hip.check(lib.eslam_sample_z_all_rng(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(ro), _hip.ptr(rd),
+                                                  _hip.ptr(gd), R, n_strat, n_imp, float(truncation), _hip.ptr(t_free),
+                                                  _hip.ptr(t_surf), 1 if perturb else 0,
+                                                  torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, _hip.ptr(state), _hip.ptr(z),
+                                                  _hip.stream_handle(dev)), "eslam_sample_z_all_rng")
+        _rng_pending[dev.index] = True
+        return z
     if rand is None:
         # one draw, three row-major blocks (the reference draws them in three calls, Renderer.py:59, common.py:59)
         n1, n2 = (R * S, R * n_strat) if perturb else (0, 0)

@@ -3,11 +3,13 @@
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Planes and decoders are replicated; the
 rays of an iteration are split across ranks; rays are independent in the forward pass, so the only exchange steps are
 
-  1. one all-reduce of ESLAM_LOSS_ACC = 16 floats (sizes of the loss's masked sets and their squared-error sums), so
-     that every rank scales its upstream gradients by the GLOBAL denominators of the reference's means
-     (src/Mapper.py:136-140,343,346) and the summed gradients equal those of the unsharded batch;
-  2. one all-reduce(sum) of ONE flat float32 buffer holding the 12 plane gradients, the 2692 decoder gradients and
-     beta's: 27.15 MB for room0, 70.5 MB for scene0000.
+  1. one int32 all-reduce(sum) between forward and backward (sync_pack / sync_unpack): the five sizes of the loss's masked
+     sets, so that every rank scales its upstream gradients by the GLOBAL denominators of the reference's means
+     (src/Mapper.py:136-140,343,346) and the summed gradients equal those of the unsharded batch - and, in the same
+     buffer, the union of the texels the ranks' backward passes will touch;
+  2. one all-reduce(sum) of the gradients: ONE flat float32 buffer holding the 12 plane gradients, the 2692 decoder
+     gradients, beta's and the loss's 16 sums (27.15 MB for room0, 70.5 MB for scene0000), of which only the union's
+     texels are exchanged (block-sparse) when the planes are channels_last.
 
 Identical optimiser steps on every rank then keep the replicas in sync without a broadcast.
 The flat buffer is also what RenderFn.backward scatters into (ops.grad_sink), so no copy sits between the backward
@@ -27,6 +29,56 @@ def shard_slice(n, rank, world):
     per = (n + world - 1) // world
     lo = min(n, rank * per)
     return lo, min(n, lo + per)
+
+
+SYNC_HEAD = 8                                   # eslam_hip.h: words 0..4 = N_front, N_center, N_tail, N_depth, N_color
+_ACC_COUNT_SLOTS = (0, 1, 2, 6, 9)              # their slots in acc [16] (eslam_loss_final.h)
+_ACC_SUM_SLOTS = (3, 4, 5, 7, 8)                # S_front, S_center, S_tail, S_depth, S_color
+
+
+def sync_words(n_blocks):
+    return SYNC_HEAD + (n_blocks + 5) // 6
+
+
+def sync_pack(acc, touched, out):
+    """acc [16] float32 + touched [n] uint8 (or None) -> out [sync_words(n)] int32 (eslam_shard_sync_pack; the same
+    arithmetic in tensor ops on the CPU, which is what the gloo tests run)."""
+    n = 0 if touched is None else touched.numel()
+    if acc.is_cuda:
+        with _hip.on_device(acc.device):
+            _hip.check(_hip.lib().eslam_shard_sync_pack(_hip.ptr(acc), _hip.ptr(touched), n, _hip.ptr(out),
+                                                        _hip.stream_handle(acc.device)), "eslam_shard_sync_pack")
+        return out
+    out[:SYNC_HEAD] = 0
+    out[:5] = acc[list(_ACC_COUNT_SLOTS)].to(torch.int32)
+    if n:
+        pad = torch.zeros(6 * ((n + 5) // 6), dtype=torch.int32)
+        pad[:n] = (touched != 0).to(torch.int32)
+        out[SYNC_HEAD:] = (pad.view(-1, 6) << (4 * torch.arange(6, dtype=torch.int32))).sum(1).to(torch.int32)
+    return out
+
+
+def sync_unpack(buf, acc_local, acc_global, touched):
+    """Inverse of sync_pack after the SUM all-reduce: global set sizes into acc_global (the other slots copied from
+    acc_local), union of the touched texels into touched (eslam_shard_sync_unpack)."""
+    n = 0 if touched is None else touched.numel()
+    if buf.is_cuda:
+        with _hip.on_device(buf.device):
+            _hip.check(_hip.lib().eslam_shard_sync_unpack(_hip.ptr(buf), n, _hip.ptr(acc_local), _hip.ptr(acc_global),
+                                                          _hip.ptr(touched), _hip.stream_handle(buf.device)),
+                       "eslam_shard_sync_unpack")
+        return
+    acc_global.copy_(acc_local)
+    acc_global[list(_ACC_COUNT_SLOTS)] = buf[:5].to(acc_global.dtype)
+    if n:
+        nib = (buf[SYNC_HEAD:, None] >> (4 * torch.arange(6, dtype=torch.int32))) & 15
+        touched.copy_((nib.reshape(-1)[:n] != 0).to(torch.uint8))
+
+
+def loss_from_acc(acc, weights):
+    """The loss value from the 16 accumulators (sums / set sizes), as eslam_loss_value forms it."""
+    w = torch.tensor(weights, dtype=acc.dtype, device=acc.device)
+    return (w * acc[list(_ACC_SUM_SLOTS)] / acc[list(_ACC_COUNT_SLOTS)]).sum()
 
 
 class FlatGrads:
@@ -120,13 +172,15 @@ class FlatGrads:
 class ShardedMapper:
     """Drives one ray-sharded mapping iteration on this rank's shard (a harness.Workload holding this rank's rays).
 
-    step() = phase_a (sample, render forward, eslam_loss_reduce) -> all-reduce of the 16 loss accumulators ->
-    phase_b (loss value, eslam_loss_grad, render backward into the flat gradient buffer) -> all-reduce of that buffer.
-    The two phases contain no collective, so each can be captured into a hipGraph of its own (capture()); the two
-    all-reduces are issued eagerly between the replays - RCCL never has to run inside a captured graph.
+    step() = phase_a (sample, render forward with the loss's sums in its epilogue, texel marking, sync_pack)
+             -> ONE int32 all-reduce (global set sizes of the loss + union of touched texels) -> sync_unpack
+             -> phase_b (render backward, the loss's gradients formed inside the kernel from the global set sizes, into the
+                flat gradient buffer) -> exchange of that buffer (block-sparse over the union, or dense).
+    The phases contain no collective, so each can be captured into a hipGraph of its own (capture()); the two
+    collectives are issued eagerly between the replays - RCCL never has to run inside a captured graph.
 
     optimizer: optional myslam_amd.optim.Adam over self.params (build it with make_optimizer): stepped after the
-    gradient all-reduce - every rank applies the same update to identical replicas, so they stay in sync without a
+    gradient exchange - every rank applies the same update to identical replicas, so they stay in sync without a
     broadcast.  With fused_zero_grad it leaves the flat buffer zero, which saves the 27-70 MB
     fill of the next iteration; under capture() it becomes a third graph (capturable=True is required for that)."""
 
@@ -135,14 +189,17 @@ class ShardedMapper:
         self.wl = workload
         self.group = group
         self.weights = losses.MAPPING_W
+        world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        if world > 15:
+            raise RuntimeError("ShardedMapper: the sync buffer counts ranks per texel in 4 bits: at most 15 ranks")
         self.params = workload.plane_list + ops.decoder_params(workload.decoders)
         beta = workload.decoders.beta
         self.has_beta = torch.is_tensor(beta)
         if self.has_beta:
             self.params = self.params + [beta]
-        self.grads = FlatGrads(self.params)
+        self.grads = FlatGrads(self.params, extra=16)          # + the loss's 16 sums: they ride in the gradient exchange
         self.optimizer = optimizer
-        # gradient exchange: block-sparse (FlatGrads.all_reduce_compact) unless ESLAM_DP_COMPACT=0 / compact=False
+        # gradient exchange: block-sparse (FlatGrads.exchange_blocks) unless ESLAM_DP_COMPACT=0 / compact=False
         self.compact = (os.environ.get("ESLAM_DP_COMPACT", "1") != "0") if compact is None else bool(compact)
         self._n_plane_elems = sum(p.numel() for p in self.params[:12])
         # With channels_last planes the union of touched texels is known from the sample positions right after the
@@ -151,50 +208,46 @@ class ShardedMapper:
         planes = self.params[:12]
         self._can_mark = bool(self.compact and planes[0].is_cuda and
                               all(p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last) for p in planes))
-        if self.compact and planes[0].is_cuda and dist.is_available() and dist.is_initialized():
-            # one collective probe at construction (every rank builds its mapper): if the backend cannot MAX-reduce bytes,
-            # all ranks fall back to the dense all-reduce together instead of failing in the first iteration
-            try:
-                probe = torch.zeros(8, dtype=torch.uint8, device=workload.device)
-                dist.all_reduce(probe, op=dist.ReduceOp.MAX, group=group)
-            except Exception as e:          # noqa: BLE001 - any backend error means "not supported here"
-                import warnings
-                warnings.warn(f"block-sparse gradient exchange disabled ({type(e).__name__}: {e}); using the dense all-reduce")
-                self.compact = self._can_mark = False
+        dev = workload.device
+        n_blocks = self._n_plane_elems // 32 if self._can_mark else 0
+        self._touched = torch.zeros(n_blocks, dtype=torch.uint8, device=dev) if self._can_mark else None
+        self._sync = torch.zeros(sync_words(n_blocks), dtype=torch.int32, device=dev)
+        self._gacc = torch.zeros(16, device=dev)               # acc with the GLOBAL set sizes: what the backward scales by
         if self._can_mark:
-            self._touched = torch.zeros(self._n_plane_elems // 32, dtype=torch.uint8, device=workload.device)
             self._block_base = (ctypes.c_int64 * 12)(*[self.grads.offsets[i] // 32 for i in range(12)])
-            self._side = torch.cuda.Stream(device=workload.device)
-        self.acc = torch.zeros(16, device=workload.device)
-        self._out = None
+            self._side = torch.cuda.Stream(device=dev)
+        self._pre = None
         self._graphs = None
-        self.loss = None
+
+    @property
+    def loss(self):
+        """The global loss of the last step (from the 16 sums that came back with the gradient exchange)."""
+        return loss_from_acc(self.grads.extra[:16], self.weights)
 
     def phase_a(self):
         wl = self.wl
         for p in self.params:
             p.grad = None
-        self._out = wl.renderer.render_batch_ray(wl.planes, wl.decoders, wl.rays_d, wl.rays_o, wl.device, wl.truncation,
-                                                 gt_depth=wl.gt_depth)
-        depth, color, sdf, z = self._out
-        ops.loss_reduce(depth, color, sdf, z, wl.gt_depth, wl.gt_color, wl.truncation, None, self.acc)
+        depth, color, sdf, z, pre = wl.renderer.render_batch_ray_with_loss(
+            wl.planes, wl.decoders, wl.rays_d, wl.rays_o, wl.device, wl.truncation, wl.gt_depth, wl.gt_color, self.weights)
+        pre.acc_global = self._gacc                # RenderFn.backward scales by these, not by this rank's own set sizes
+        self._pre = pre
         ops.join_ray_order(wl.device)              # forward and backward are separate graphs: join the fork in this one
         if self._can_mark:
             arr, _ = _hip.make_planes(tuple([p.detach() for p in grp] for grp in wl.planes))
             with _hip.on_device(wl.device):
-                _hip.check(_hip.lib().eslam_mark_touched(arr, _hip.make_bound(ops.bound_to_host(wl.scene.bound)),
+                # the marking must use the bound the forward and backward kernels normalise with (decoders.bound)
+                _hip.check(_hip.lib().eslam_mark_touched(arr, _hip.make_bound(ops.bound_to_host(wl.decoders.bound)),
                                                          _hip.ptr(wl.rays_o.detach()), _hip.ptr(wl.rays_d.detach()),
                                                          _hip.ptr(z), wl.R, wl.S, self._block_base,
                                                          self._touched.numel(), _hip.ptr(self._touched),
                                                          _hip.stream_handle(wl.device)), "eslam_mark_touched")
+        sync_pack(pre.acc, self._touched, self._sync)
 
     def phase_b(self):
-        wl = self.wl
-        depth, color, sdf, z = self._out
         with ops.grad_sink(self.grads):
-            self.loss = ops.MappingLossFn.apply(depth, color, sdf, z, wl.gt_depth, wl.gt_color, wl.truncation,
-                                                self.weights, None, None, self.acc)
-            self.loss.backward()
+            self._pre.loss.backward()
+        self.grads.extra[:16].copy_(self._pre.acc)         # this rank's sums and set sizes: summed with the gradients
 
     def make_optimizer(self, lrs=(0.001, 0.005, 0.005), **kw):
         """Adam with the mapper's three groups (decoders / planes / c_planes, src/Mapper.py:296-303;
@@ -220,10 +273,10 @@ class ShardedMapper:
     def _run(self, run_a, run_b, run_c):
         """One iteration: phases a / b / c (eager calls or graph replays) with the collectives between them."""
         run_a()
-        dist.all_reduce(self.acc, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(self._sync, op=dist.ReduceOp.SUM, group=self.group)
+        sync_unpack(self._sync, self._pre.acc, self._gacc, self._touched)
         ev = None
         if self._can_mark:
-            dist.all_reduce(self._touched, op=dist.ReduceOp.MAX, group=self.group)
             ev = torch.cuda.Event()
             ev.record()
         run_b()                                    # enqueued before the host waits for the union below
@@ -242,7 +295,7 @@ class ShardedMapper:
         self.grads.assign()
         if run_c is not None:
             run_c()
-        return self.loss
+        return self.grads.extra
 
     def capture(self, warmup=3):
         """Capture phase_a and phase_b into two hipGraphs sharing one memory pool; step() then replays them."""

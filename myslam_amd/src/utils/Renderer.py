@@ -43,14 +43,18 @@ class Renderer(object):
         beta = ops.beta_tensor(decoders.beta, rays_o.device)
         # pts are normalised with decoders.bound (decoders.py:138), the importance sampler uses renderer.bound
         bound6 = ops.bound_to_host(decoders.bound)
-        depth, rgb, sdf = ops.RenderFn.apply(rays_o, rays_d, z_vals, bound6, beta, order, *flat_planes,
-                                             *ops.decoder_params(decoders))
-        return depth, rgb, sdf, z_vals
+        fl = ops.current_fused_loss()          # set by render_batch_ray_with_loss
+        outs = ops.RenderFn.apply(rays_o, rays_d, z_vals, bound6, beta, order, fl, *flat_planes,
+                                  *ops.decoder_params(decoders))
+        if fl is not None:
+            fl.loss = outs[3]
+        return outs[0], outs[1], outs[2], z_vals
 
     def render_batch_ray_with_loss(self, all_planes, decoders, rays_d, rays_o, device, truncation, gt_depth, gt_color,
                                    weights, ray_mask=None, _rand=None):
-        """render_batch_ray + the sums of the mapping loss (src/Mapper.py:337-346) formed in the forward kernel's
-        epilogue.  Returns (depth, rgb, sdf, z_vals, pre); pass `pre` as losses.mapping_loss(..., precomputed=pre)."""
+        """render_batch_ray + the mapping loss (src/Mapper.py:337-346): its sums are formed in the forward kernel's
+        epilogue and its gradients inside the backward kernel.  Returns (depth, rgb, sdf, z_vals, pre); pre.loss is the
+        loss (losses.mapping_loss(..., precomputed=pre) returns it): call .backward() on it."""
         with ops.fused_loss(gt_depth, gt_color, truncation, weights, ray_mask) as pre:
             depth, rgb, sdf, z_vals = self.render_batch_ray(all_planes, decoders, rays_d, rays_o, device, truncation,
                                                             gt_depth=gt_depth, _rand=_rand)

@@ -10,7 +10,7 @@ import torch
 
 
 class AnalyticRoom:
-    def __init__(self, bound, margin=0.3):
+    def __init__(self, bound, margin=0.3, variant="r01"):
         b = bound.double()
         self.lo = b[:, 0] + margin
         self.hi = b[:, 1] - margin
@@ -19,6 +19,12 @@ class AnalyticRoom:
         # centres relative to the room, radii relative to its height
         self.spheres = [(c + ext * torch.tensor(o, dtype=torch.float64), float(ext[2]) * r)
                         for o, r in (((0.28, 0.18, -0.25), 0.22), ((-0.30, -0.22, -0.30), 0.18), ((0.05, -0.30, 0.10), 0.15))]
+        if variant == "rich":
+            # five more spheres against the walls: with the three above, some views of the r01 room (a 90-degree field of
+            # view 2.8 m from a wall) showed nothing but one plane, which leaves the translation along it to the smooth albedo
+            self.spheres += [(c + ext * torch.tensor(o, dtype=torch.float64), float(ext[2]) * r)
+                             for o, r in (((0.05, 0.42, 0.05), 0.16), ((-0.20, 0.40, -0.28), 0.14), ((0.33, 0.38, 0.22), 0.12),
+                                          ((0.44, -0.05, 0.00), 0.17), ((-0.44, 0.10, 0.05), 0.17))]
 
     def cast(self, o, d):
         """o [3], d [...,3] (float32/64) -> depth t [...] and colour [...,3] of the first hit."""
@@ -81,10 +87,10 @@ def render_frame(room, sc, c2w, device="cpu", hole_frac=0.0, seed=0):
     return t.contiguous(), col.float().contiguous()
 
 
-def make_sequence(sc, n_frames, device="cpu", hole_frac=0.02):
+def make_sequence(sc, n_frames, device="cpu", hole_frac=0.02, variant="r01"):
     """[(idx, colour [H,W,3], depth [H,W], gt_c2w [4,4])] - the tuples the reference's dataset readers yield
     (src/utils/datasets.py:107-148)."""
-    room = AnalyticRoom(sc.bound)
+    room = AnalyticRoom(sc.bound, variant=variant)
     poses = trajectory(n_frames, sc.bound)
     frames = []
     for k in range(n_frames):

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/eslam_hip.h but not exported"
         assert n in _hip.SIGNATURES, f"{n} has no ctypes prototype in myslam_amd/_hip.py"
-    assert lib.eslam_abi_version() == 1
+    assert lib.eslam_abi_version() == _hip.ABI_VERSION == 2
     assert lib.eslam_bwd_workspace_bytes(262144) > 262144 * 128 * 4
     assert lib.eslam_bwd_workspace_bytes(-1) == -1
 
@@ -250,3 +250,39 @@ def test_ray_sharded_data_parallel_equals_single_process(world, compact):
     if compact:
         sent, dense = ret["exchange"]
         assert sent < 0.5 * dense, (sent, dense)          # 200 rays touch a small part of the 27 MB of planes
+
+
+def _sync_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    from myslam_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 1000
+    g = torch.Generator().manual_seed(100 + rank)
+    acc = torch.floor(torch.rand(16, generator=g) * 1000)
+    touched = (torch.rand(n, generator=g) < 0.1).to(torch.uint8)
+    buf = parallel.sync_pack(acc, touched, torch.zeros(parallel.sync_words(n), dtype=torch.int32))
+    dist.all_reduce(buf)
+    gacc, union = torch.zeros(16), torch.zeros(n, dtype=torch.uint8)
+    parallel.sync_unpack(buf, acc, gacc, union)
+    ret[rank] = (acc.numpy(), touched.numpy(), gacc.numpy(), union.numpy())
+    dist.destroy_process_group()
+
+
+def test_sync_collective_gives_global_set_sizes_and_the_union():
+    """The ONE int32 all-reduce between forward and backward of the ray-sharded step (parallel.sync_pack / sync_unpack):
+    3 gloo ranks end with the summed set sizes and the union of their touched texels; the loss's sums stay local."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sync_worker, args=(3, _free_port(), ret), nprocs=3, join=True)
+    accs = np.stack([ret[r][0] for r in range(3)])
+    union = np.maximum.reduce([ret[r][1] for r in range(3)])
+    for r in range(3):
+        gacc, u = ret[r][2], ret[r][3]
+        assert np.array_equal(u, union)
+        for k in (0, 1, 2, 6, 9):
+            assert gacc[k] == accs[:, k].sum()
+        for k in (3, 4, 5, 7, 8):
+            assert gacc[k] == accs[r, k]

@@ -233,3 +233,77 @@ def test_ray_order_is_a_permutation_and_groups_neighbours(cameras, R):
         step_sorted = (dn[p[1:n1]] - dn[p[:n1 - 1]]).norm(dim=1).mean()
         step_given = (dn[1:n1] - dn[:n1 - 1]).norm(dim=1).mean()
         assert float(step_sorted) < 0.1 * float(step_given)
+
+
+def test_shard_sync_pack_unpack_match_the_tensor_ops():
+    """eslam_shard_sync_pack / _unpack (the one collective between forward and backward of the ray-sharded step) against
+    the tensor-op form parallel.sync_pack / sync_unpack run on the CPU under gloo."""
+    from myslam_amd import parallel
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    for n in (0, 1, 5, 6, 7, 1003, 212_345):
+        acc = torch.floor(torch.rand(16, generator=g) * 1e5)
+        acc[3] = 0.37
+        t = (torch.rand(n, generator=g) < 0.3).to(torch.uint8) * 7 if n else None
+        ref = parallel.sync_pack(acc, t, torch.zeros(parallel.sync_words(n), dtype=torch.int32))
+        got = parallel.sync_pack(acc.to(dev), None if t is None else t.to(dev),
+                                 torch.full((parallel.sync_words(n),), -1, dtype=torch.int32, device=dev))
+        assert torch.equal(got.cpu()[:5], ref[:5]) and torch.equal(got.cpu()[8:], ref[8:])
+        tot = ref * 3                                     # as if three ranks had contributed the same buffer
+        ga, gt = torch.zeros(16), (torch.zeros(n, dtype=torch.uint8) if n else None)
+        parallel.sync_unpack(tot, acc, ga, gt)
+        da, dt = torch.zeros(16, device=dev), (torch.full((n,), 9, dtype=torch.uint8, device=dev) if n else None)
+        parallel.sync_unpack(tot.to(dev), acc.to(dev), da, dt)
+        assert torch.equal(da.cpu(), ga)
+        assert float(ga[0]) == 3 * float(acc[0]) and float(ga[3]) == float(acc[3])
+        if n:
+            assert torch.equal(dt.cpu(), gt) and torch.equal(gt, (t != 0).to(torch.uint8))
+
+
+def test_in_kernel_jitter_is_uniform_fresh_per_step_and_reproducible():
+    """eslam_sample_z_all_rng: the jitter / importance numbers drawn inside the sampler (no torch.rand launch).  Each z must
+    lie in its stratum [lower, upper) with a uniform position, successive iterations must differ (the forward kernel
+    advances the device step counter), and the same (seed, step) must give the same samples."""
+    from myslam_amd import harness, ops
+    dev = torch.device("cuda:0")
+    wl = harness.make_workload("room0", 1500, 24, 8, device=dev, zero_frac=0.1)
+    r = wl.renderer
+
+    def render():
+        with torch.no_grad():
+            return r.render_batch_ray(wl.planes, wl.decoders, wl.rays_d, wl.rays_o, dev, wl.truncation, gt_depth=wl.gt_depth)[3]
+    torch.manual_seed(1234)
+    ops._rng_state(dev).zero_()
+    z1, z2 = render(), render()
+    assert int(ops._rng_state(dev)[0]) == 2                       # one bump per rendered batch
+    torch.manual_seed(1234)
+    ops._rng_state(dev).zero_()
+    z1b = render()
+    assert torch.equal(z1, z1b)                                   # same seed and step: same samples
+    assert not torch.equal(z1, z2)
+    has = wl.gt_depth > 0
+    assert (z1[:, 1:] >= z1[:, :-1]).all() and (z2[:, 1:] >= z2[:, :-1]).all()
+    # recover the uniform positions of the depth-guided rows: z = lower + (upper - lower) t around the un-jittered samples
+    r.perturb = False
+    torch.manual_seed(1234)
+    z0 = render()
+    r.perturb = True
+    z0, zj = z0[has].double(), z1[has].double()
+    mids = 0.5 * (z0[:, 1:] + z0[:, :-1])
+    lower = torch.cat([z0[:, :1], mids], 1)
+    upper = torch.cat([mids, z0[:, -1:]], 1)
+    w = upper - lower
+    ok = w > 1e-6
+    t = ((zj - lower) / w.clamp(min=1e-12))[ok]
+    assert float(t.min()) >= -1e-4 and float(t.max()) < 1 + 1e-4
+    n = t.numel()
+    assert abs(float(t.mean()) - 0.5) < 4 * (1 / 12) ** 0.5 / n ** 0.5 + 1e-3
+    assert abs(float(t.var()) - 1 / 12) < 5e-3
+    hist = torch.histc(t.float(), bins=16, min=0.0, max=1.0) / n
+    assert float((hist - 1 / 16).abs().max()) < 0.01
+    # neighbouring samples / rays are uncorrelated
+    tt = ((zj - lower) / w.clamp(min=1e-12))
+    a, b = tt[:, 2:20].reshape(-1) - 0.5, tt[:, 3:21].reshape(-1) - 0.5
+    assert abs(float((a * b).mean()) * 12) < 0.03
+    a, b = tt[:-1, 2:20].reshape(-1) - 0.5, tt[1:, 2:20].reshape(-1) - 0.5
+    assert abs(float((a * b).mean()) * 12) < 0.03

@@ -326,7 +326,8 @@ def test_sharded_mapper_one_rank_rccl():
         wl = harness.make_workload("room0", 512, 32, 8, device=dev, planes="synth")
         wl.renderer.perturb = False                     # same z_vals in both runs
         mapper = ShardedMapper(wl)
-        loss_dp = mapper.step()
+        mapper.step()
+        loss_dp = mapper.loss
         g_dp = [p.grad.detach().clone() for p in mapper.params]
         loss = wl.step()
         g_ref = [p.grad.detach().clone() for p in mapper.params]
@@ -337,7 +338,8 @@ def test_sharded_mapper_one_rank_rccl():
         # the same step as two captured hipGraphs with the all-reduces between the replays
         mapper.capture()
         for _ in range(2):
-            loss_g = mapper.step()
+            mapper.step()
+        loss_g = mapper.loss
         torch.cuda.synchronize()
         assert abs(float(loss_g) - float(loss)) <= 1e-6 * abs(float(loss))
         for p, b in zip(mapper.params, g_ref):
@@ -354,9 +356,10 @@ def test_sharded_mapper_one_rank_rccl():
             ma.step()
         ma.capture(warmup=0)
         for _ in range(3):
-            la = ma.step()
+            ma.step()
+        la = ma.loss
         torch.cuda.synchronize()
-        assert float(ma.grads.flat.abs().max()) == 0.0          # consumed gradients were cleared in the Adam pass
+        assert float(ma.grads.flat[:ma.grads.offsets[-1]].abs().max()) == 0.0      # consumed gradients were cleared in the Adam pass
         dec_b = list(wb.decoders.parameters())
         ob = optim.Adam([{"params": dec_b, "lr": 0.001}, {"params": wb.plane_list[:6], "lr": 0.005},
                          {"params": wb.plane_list[6:], "lr": 0.005}])
@@ -422,16 +425,17 @@ def _two_rank_worker(rank, world, port, ret):
         for label, compact in (("dense", False), ("sparse", True)):
             m = ShardedMapper(wl, compact=compact)
             assert m._can_mark == compact
-            loss = m.step()
+            m.step()
             torch.cuda.synchronize()
-            out[label] = (float(loss), m.grads.flat.cpu().numpy().copy())
+            ng = m.grads.offsets[-1]                 # the 16 loss sums ride behind the gradients in the flat buffer
+            out[label] = (float(m.loss), m.grads.flat[:ng].cpu().numpy().copy())
             if compact:
                 out["exchange"] = m.grads.last_exchange
                 m.capture(warmup=1)
                 for _ in range(2):
-                    loss = m.step()
+                    m.step()
                 torch.cuda.synchronize()
-                out["graph"] = (float(loss), m.grads.flat.cpu().numpy().copy())
+                out["graph"] = (float(m.loss), m.grads.flat[:ng].cpu().numpy().copy())
         if rank == 0:
             ret.update(out)
     finally:
