@@ -166,13 +166,26 @@ int64_t eslam_bwd_workspace_bytes(int64_t n_points);
  * eslam_decoders_t: w1,b1,w2,b2,w3,b3,cw1,...,cb3; NULL = decoders frozen, their gradient work is skipped) and
  * g_beta [1] (may be NULL), and when g_rays_o / g_rays_d are
  * non-NULL overwrites them ([R,3] each) with the gradient through pts = o + d z.  z_vals carries no gradient
- * (Renderer.py builds it under no_grad / from gt_depth).  ray_order: the buffer eslam_render_fwd filled, or NULL
- * (then the order is computed here).  workspace: eslam_bwd_workspace_bytes(R*S) bytes.                      */
+ * (Renderer.py builds it under no_grad / from gt_depth).  ray_order: the buffer eslam_ray_order filled, or NULL
+ * (then the order is computed here).  scatter_records: from eslam_scatter_prep, or NULL (see there).
+ * workspace: eslam_bwd_workspace_bytes(R*S) bytes.                                                          */
 int eslam_render_bwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
                      const float* rays_o, const float* rays_d, const float* z_vals, int R, int S,
                      const float* sdf, const float* raw_rgb, const float* feat, const float* g_depth,
                      const float* g_rgb, const float* g_sdf, float* g_dec, float* g_beta, float* g_rays_o,
-                     float* g_rays_d, const int32_t* ray_order, void* workspace, eslam_stream_t stream);
+                     float* g_rays_d, const int32_t* ray_order, const void* scatter_records, void* workspace,
+                     eslam_stream_t stream);
+
+/* The first half of the plane-gradient scatter of eslam_render_bwd, runnable before the backward pass: which texel cell of
+ * each of the 12 planes every sample falls into, and each ray bundle's samples sorted by cell, depend on the sample
+ * positions only - not on any gradient.  eslam_scatter_prep computes them (ray_order: from eslam_ray_order, required)
+ * into records [eslam_scatter_records_bytes(R, S) bytes]; hand the buffer to eslam_render_bwd* as `scatter_records`
+ * together with the same ray_order, and its scatter only loads the sorted records and walks them.  A caller can issue
+ * it on a side stream right after the samplers, beside the forward kernel; NULL scatter_records = the backward does
+ * both halves itself.  Planes, rays and z_vals must be the ones the backward is given.                             */
+int64_t eslam_scatter_records_bytes(int R, int S);
+int eslam_scatter_prep(const eslam_plane_t* planes, const float* bound6_host, const float* rays_o, const float* rays_d,
+                       const float* z_vals, int R, int S, const int32_t* ray_order, void* records, eslam_stream_t stream);
 
 /* eslam_render_bwd for an iteration whose loss is the mapping loss (src/Mapper.py:110-144,337-346; with ray_mask the
  * tracker's, src/Tracker.py:114-148,197-204): the upstream gradients d loss / d (depth, rgb, sdf) are formed INSIDE the
@@ -189,7 +202,7 @@ int eslam_render_bwd_loss(const eslam_plane_t* planes, const eslam_decoders_t* d
                           const float* weights5_host, const uint8_t* ray_mask, const float* acc,
                           const float* upstream, float* loss_out, const float* g_depth, const float* g_rgb,
                           const float* g_sdf, float* g_dec, float* g_beta, float* g_rays_o, float* g_rays_d,
-                          const int32_t* ray_order, void* workspace, eslam_stream_t stream);
+                          const int32_t* ray_order, const void* scatter_records, void* workspace, eslam_stream_t stream);
 
 /* Decoder-only query.  Replaces src/networks/decoders.py:127-146 (Decoders.forward), the entry used by
  * src/utils/Mesher.py:151 on up to 500k points.  pts [N,3] world coordinates -> raw [N,4] = (r,g,b,sdf).
@@ -326,6 +339,10 @@ int eslam_blocks_pack(const float* flat, const int64_t* idx, int64_t n_idx, cons
                       eslam_stream_t stream);
 int eslam_blocks_unpack(float* flat, const int64_t* idx, int64_t n_idx, float* tail, int64_t n_tail, const float* buf,
                         eslam_stream_t stream);
+/* Sparse clear of the flat gradient buffer: zero the 128-byte blocks idx [n_idx] (the union exchanged in the previous
+ * iteration - every other block of the plane region is still zero) and the dense tail [n_tail] - 1.6-4.5 MB of stores
+ * instead of a 27-70 MB fill.                                                                               */
+int eslam_blocks_zero(float* flat, const int64_t* idx, int64_t n_idx, float* tail, int64_t n_tail, eslam_stream_t stream);
 
 /* Per-kernel device timing for bench.py's roofline line (HIP events recorded on the launch stream around each
  * kernel while enabled; adds nothing to the launch path when disabled).  Usage: enable(1); run one iteration;

@@ -56,9 +56,11 @@ SIGNATURES = {
     "eslam_ray_order": (_i, [_vp, _vp, _i, _vp, _vp]),
     "eslam_bwd_workspace_bytes": (_i64, [_i64]),
     "eslam_render_bwd": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                              _vp, _vp, _vp]),
+                              _vp, _vp, _vp, _vp]),
+    "eslam_scatter_records_bytes": (_i64, [_i, _i]),
+    "eslam_scatter_prep": (_i, [_PP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "eslam_render_bwd_loss": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _BP, _vp, _vp,
-                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "eslam_decode_fwd": (_i, [_PP, _DP, _BP, _vp, _i64, _i, _vp, _vp, _vp]),
     "eslam_decode_bwd": (_i, [_PP, _DP, _BP, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "eslam_mapping_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _BP, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -78,6 +80,7 @@ SIGNATURES = {
     "eslam_blocks_touched": (_i, [_vp, _i64, _vp, _vp]),
     "eslam_blocks_pack": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "eslam_blocks_unpack": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "eslam_blocks_zero": (_i, [_vp, _vp, _i64, _vp, _i64, _vp]),
     "eslam_shard_sync_words": (_i64, [_i64]),
     "eslam_shard_sync_pack": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "eslam_shard_sync_unpack": (_i, [_vp, _i64, _vp, _vp, _vp, _vp]),

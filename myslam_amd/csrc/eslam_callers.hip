@@ -173,7 +173,9 @@ __global__ __launch_bounds__(256) void blocks_touched_kernel(const float* __rest
     }
 }
 
-template <bool PACK>
+// MODE 0: gather blocks into buf; 1: scatter buf back; 2: zero the listed blocks and the tail (sparse clear of a gradient
+// buffer whose non-zero blocks are known: the union the ranks exchanged in the previous iteration)
+template <int MODE>
 __global__ __launch_bounds__(256) void blocks_move_kernel(float* __restrict__ flat, const int64_t* __restrict__ idx,
                                                           int64_t n_idx, float* __restrict__ tail, int64_t n_tail,
                                                           float* __restrict__ buf) {
@@ -182,13 +184,15 @@ __global__ __launch_bounds__(256) void blocks_move_kernel(float* __restrict__ fl
     for (int64_t i = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); i < n_idx; i += stride) {
         float4_t* a = (float4_t*)(flat + idx[i] * 32 + sub * 4);
         float4_t* b = (float4_t*)(buf + i * 32 + sub * 4);
-        if (PACK) *b = *a;
-        else *a = *b;
+        if (MODE == 0) *b = *a;
+        else if (MODE == 1) *a = *b;
+        else *a = (float4_t){0.f, 0.f, 0.f, 0.f};
     }
     float* tbuf = buf + n_idx * 32;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_tail; i += (int64_t)gridDim.x * 256) {
-        if (PACK) tbuf[i] = tail[i];
-        else tail[i] = tbuf[i];
+        if (MODE == 0) tbuf[i] = tail[i];
+        else if (MODE == 1) tail[i] = tbuf[i];
+        else tail[i] = 0.0f;
     }
 }
 
@@ -204,36 +208,44 @@ extern "C" int eslam_blocks_touched(const float* flat, int64_t n_blocks, uint8_t
     return eslam_check_launch("blocks_touched_kernel");
 }
 
-static int blocks_move(bool pack, float* flat, const int64_t* idx, int64_t n_idx, float* tail, int64_t n_tail, float* buf,
+static int blocks_move(int mode, float* flat, const int64_t* idx, int64_t n_idx, float* tail, int64_t n_tail, float* buf,
                        eslam_stream_t stream) {
     if (n_idx < 0 || n_tail < 0) {
         eslam_set_error("eslam_blocks_pack/unpack: negative size");
         return 1;
     }
     if (n_idx == 0 && n_tail == 0) return 0;
-    if (!buf || (n_idx > 0 && (!flat || !idx)) || (n_tail > 0 && !tail) || ((uintptr_t)flat & 15) || ((uintptr_t)buf & 15)) {
+    if ((mode != 2 && !buf) || (n_idx > 0 && (!flat || !idx)) || (n_tail > 0 && !tail) || ((uintptr_t)flat & 15) || ((uintptr_t)buf & 15)) {
         eslam_set_error("eslam_blocks_pack/unpack: null or unaligned argument");
         return 1;
     }
     const int64_t want = (n_idx + 31) / 32 > (n_tail + 255) / 256 ? (n_idx + 31) / 32 : (n_tail + 255) / 256;
     const dim3 grid((unsigned)(want < 4096 ? (want > 0 ? want : 1) : 4096));
-    if (pack)
-        hipLaunchKernelGGL(blocks_move_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, flat, idx, n_idx, tail,
+    if (mode == 0)
+        hipLaunchKernelGGL(blocks_move_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, flat, idx, n_idx, tail,
+                           n_tail, buf);
+    else if (mode == 1)
+        hipLaunchKernelGGL(blocks_move_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, flat, idx, n_idx, tail,
                            n_tail, buf);
     else
-        hipLaunchKernelGGL(blocks_move_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, flat, idx, n_idx, tail,
+        hipLaunchKernelGGL(blocks_move_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, flat, idx, n_idx, tail,
                            n_tail, buf);
     return eslam_check_launch("blocks_move_kernel");
 }
 
 extern "C" int eslam_blocks_pack(const float* flat, const int64_t* idx, int64_t n_idx, const float* tail, int64_t n_tail,
                                  float* buf, eslam_stream_t stream) {
-    return blocks_move(true, (float*)flat, idx, n_idx, (float*)tail, n_tail, buf, stream);
+    return blocks_move(0, (float*)flat, idx, n_idx, (float*)tail, n_tail, buf, stream);
 }
 
 extern "C" int eslam_blocks_unpack(float* flat, const int64_t* idx, int64_t n_idx, float* tail, int64_t n_tail,
                                    const float* buf, eslam_stream_t stream) {
-    return blocks_move(false, flat, idx, n_idx, tail, n_tail, (float*)buf, stream);
+    return blocks_move(1, flat, idx, n_idx, tail, n_tail, (float*)buf, stream);
+}
+
+extern "C" int eslam_blocks_zero(float* flat, const int64_t* idx, int64_t n_idx, float* tail, int64_t n_tail,
+                                 eslam_stream_t stream) {
+    return blocks_move(2, flat, idx, n_idx, tail, n_tail, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -595,7 +595,7 @@ static Bound make_bound(const float* b6) {
 
 int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float* rays_o, const float* rays_d,
                      const float* z_or_pts, int64_t R, int S, bool render, const float* g_feat, const int* perm,
-                     hipStream_t st);
+                     hipStream_t st, unsigned* records, int phase);
 
 
 static int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
@@ -637,7 +637,7 @@ static AuxStream* aux_stream() {
 static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, const Bound& bnd, const float* rays_o,
                       const float* rays_d, const float* z_or_pts, int64_t R, int S, int mode, const float* feat,
                       float* g_o, float* g_feat, float* slabs, const int* perm, float* g_dec, float* g_out_a, float* g_out_b,
-                      RayBwdIn rb, const LossGradIn* li, float* g_beta, hipStream_t st) {
+                      RayBwdIn rb, const LossGradIn* li, float* g_beta, const void* scatter_records, hipStream_t st) {
     const bool render = mode != 0;
     const int64_t N = render ? R * S : R;
     PlaneSet ps;
@@ -704,7 +704,9 @@ static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, 
     }
     if (any_grad) {
         eslam_prof_begin(PROF_SCATTER, st);
-        if (int rc = eslam_scatter_v2(planes, bnd, rays_o, rays_d, z_or_pts, R, S, render, g_feat, perm, st)) return rc;
+        if (int rc = eslam_scatter_v2(planes, bnd, rays_o, rays_d, z_or_pts, R, S, render, g_feat, perm, st,
+                                      (unsigned*)scatter_records, scatter_records ? 2 : 0))
+            return rc;
         eslam_prof_end(PROF_SCATTER, st);
     }
     // position gradients
@@ -734,9 +736,13 @@ static int render_bwd_impl(const char* who, const eslam_plane_t* planes, const e
                            const float* bound6_host, const float* rays_o, const float* rays_d, const float* z_vals, int R,
                            int S, const float* sdf, const float* raw_rgb, const float* feat, const float* g_depth,
                            const float* g_rgb, const float* g_sdf, const LossGradIn* li, float* g_dec, float* g_beta,
-                           float* g_rays_o, float* g_rays_d, const int32_t* ray_order, void* workspace,
-                           eslam_stream_t stream) {
+                           float* g_rays_o, float* g_rays_d, const int32_t* ray_order, const void* scatter_records,
+                           void* workspace, eslam_stream_t stream) {
     if (R <= 0) return 0;
+    if (scatter_records && !ray_order) {
+        eslam_set_error("%s: scatter_records come from eslam_scatter_prep, which was given a ray_order: pass it here too", who);
+        return 1;
+    }
     if (S <= 0 || S > ESLAM_MAX_SAMPLES) {
         eslam_set_error("%s: S=%d outside [1,%d]", who, S, ESLAM_MAX_SAMPLES);
         return 1;
@@ -771,16 +777,18 @@ static int render_bwd_impl(const char* who, const eslam_plane_t* planes, const e
     rb.z_vals = z_vals; rb.sdf = sdf; rb.raw_rgb = raw_rgb; rb.beta = dec->beta;
     rb.g_depth = g_depth; rb.g_rgb = g_rgb; rb.g_sdf = g_sdf; rb.R = R; rb.S = S;
     return bwd_common(planes, dec, bnd, rays_o, rays_d, z_vals, R, S, li ? 2 : 1, feat, g_o, g_feat, slabs, perm, g_dec,
-                      g_rays_o, g_rays_d, rb, li, g_beta, st);
+                      g_rays_o, g_rays_d, rb, li, g_beta, scatter_records, st);
 }
 
 extern "C" int eslam_render_bwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
                                 const float* rays_o, const float* rays_d, const float* z_vals, int R, int S,
                                 const float* sdf, const float* raw_rgb, const float* feat, const float* g_depth,
                                 const float* g_rgb, const float* g_sdf, float* g_dec, float* g_beta, float* g_rays_o,
-                                float* g_rays_d, const int32_t* ray_order, void* workspace, eslam_stream_t stream) {
+                                float* g_rays_d, const int32_t* ray_order, const void* scatter_records, void* workspace,
+                                eslam_stream_t stream) {
     return render_bwd_impl("eslam_render_bwd", planes, dec, bound6_host, rays_o, rays_d, z_vals, R, S, sdf, raw_rgb, feat,
-                           g_depth, g_rgb, g_sdf, nullptr, g_dec, g_beta, g_rays_o, g_rays_d, ray_order, workspace, stream);
+                           g_depth, g_rgb, g_sdf, nullptr, g_dec, g_beta, g_rays_o, g_rays_d, ray_order, scatter_records,
+                           workspace, stream);
 }
 
 extern "C" int eslam_render_bwd_loss(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
@@ -790,7 +798,8 @@ extern "C" int eslam_render_bwd_loss(const eslam_plane_t* planes, const eslam_de
                                      const float* weights5_host, const uint8_t* ray_mask, const float* acc,
                                      const float* upstream, float* loss_out, const float* g_depth, const float* g_rgb,
                                      const float* g_sdf, float* g_dec, float* g_beta, float* g_rays_o, float* g_rays_d,
-                                     const int32_t* ray_order, void* workspace, eslam_stream_t stream) {
+                                     const int32_t* ray_order, const void* scatter_records, void* workspace,
+                                     eslam_stream_t stream) {
     if (!depth || !rgb || !gt_depth || !gt_color || !weights5_host || !acc) {
         eslam_set_error("eslam_render_bwd_loss: null loss argument");
         return 1;
@@ -801,7 +810,8 @@ extern "C" int eslam_render_bwd_loss(const eslam_plane_t* planes, const eslam_de
     li.tr = make_trunc(truncation);
     li.w = LossW{weights5_host[0], weights5_host[1], weights5_host[2], weights5_host[3], weights5_host[4]};
     return render_bwd_impl("eslam_render_bwd_loss", planes, dec, bound6_host, rays_o, rays_d, z_vals, R, S, sdf, raw_rgb,
-                           feat, g_depth, g_rgb, g_sdf, &li, g_dec, g_beta, g_rays_o, g_rays_d, ray_order, workspace, stream);
+                           feat, g_depth, g_rgb, g_sdf, &li, g_dec, g_beta, g_rays_o, g_rays_d, ray_order, scatter_records,
+                           workspace, stream);
 }
 
 extern "C" int eslam_decode_bwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
@@ -826,5 +836,5 @@ extern "C" int eslam_decode_bwd(const eslam_plane_t* planes, const eslam_decoder
     hipLaunchKernelGGL(decode_act_bwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, raw, g_raw, N, g_o);
     if (int rc = eslam_check_launch("decode_act_bwd_kernel")) return rc;
     return bwd_common(planes, dec, bnd, nullptr, nullptr, pts, N, 64, 0, feat, g_o, g_feat, slabs, nullptr, g_dec,
-                      g_pts, nullptr, RayBwdIn{}, nullptr, nullptr, st);
+                      g_pts, nullptr, RayBwdIn{}, nullptr, nullptr, nullptr, st);
 }

@@ -206,19 +206,30 @@ __device__ __forceinline__ void depth_guided_row(float d, int ray, int n_strat, 
     const int S = n_strat + n_imp;
     const float d12 = __fmul_rn(1.2f, d);          // Renderer.py:100
     const float dlo = __fsub_rn(d, c15);           // Renderer.py:97
+    // both sequences into the upper half of the wave's scratch first (zs has ESLAM_MAX_SAMPLES >= 2 S floats only when
+    // S <= 128; larger S recomputes the other sequence's values from t_free / t_surf as before)
+    const bool staged = 2 * S <= ESLAM_MAX_SAMPLES;
+    float* raw = zs + S;
+    if (staged) {
+        for (int i = lane; i < S; i += WAVE)
+            raw[i] = (i < n_strat) ? __fadd_rn(0.0f, __fmul_rn(d12, t_free[i])) : __fadd_rn(dlo, __fmul_rn(c3, t_surf[i - n_strat]));
+        WAVE_SYNC();
+    }
     for (int i = lane; i < S; i += WAVE) {
         float val;
         int pos;
         if (i < n_strat) {
             val = __fadd_rn(0.0f, __fmul_rn(d12, t_free[i]));
             int cnt = 0;
-            for (int j = 0; j < n_imp; ++j) cnt += (__fadd_rn(dlo, __fmul_rn(c3, t_surf[j])) < val) ? 1 : 0;
+            if (staged) { for (int j = 0; j < n_imp; ++j) cnt += (raw[n_strat + j] < val) ? 1 : 0; }
+            else { for (int j = 0; j < n_imp; ++j) cnt += (__fadd_rn(dlo, __fmul_rn(c3, t_surf[j])) < val) ? 1 : 0; }
             pos = i + cnt;
         } else {
             const int j = i - n_strat;
             val = __fadd_rn(dlo, __fmul_rn(c3, t_surf[j]));
             int cnt = 0;
-            for (int k = 0; k < n_strat; ++k) cnt += (__fadd_rn(0.0f, __fmul_rn(d12, t_free[k])) <= val) ? 1 : 0;
+            if (staged) { for (int k = 0; k < n_strat; ++k) cnt += (raw[k] <= val) ? 1 : 0; }
+            else { for (int k = 0; k < n_strat; ++k) cnt += (__fadd_rn(0.0f, __fmul_rn(d12, t_free[k])) <= val) ? 1 : 0; }
             pos = j + cnt;
         }
         zs[pos] = val;

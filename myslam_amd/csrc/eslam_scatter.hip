@@ -252,14 +252,21 @@ __global__ __launch_bounds__(1024) void ray_order_kernel(const float* __restrict
 // ---------------------------------------------------------------------------------------------------------
 // NT threads per workgroup, BM = 4*NT samples per workgroup (power of two).
 //   DBG: 0 production; 1 walk without atomics; 2 stop after the sort (profiling only, tools/dbg_scatter.py)
-template <bool RENDER, int DBG, int NT>
+//   PHASE: 0 = cells + sort + walk in one launch.  The cells and the sort depend on the sample POSITIONS only, not on the
+//   feature gradients, so they can run long before the backward pass, beside the forward kernel on another stream:
+//   PHASE 1 (eslam_scatter_prep) stops after the sort and writes the workgroup's sorted record image (the 6*BM words of
+//   LDS + one word of flags) to `records`; PHASE 2 (inside eslam_render_bwd) reads that image back - 48 KB of coalesced
+//   loads instead of 33 us of latency-bound cell arithmetic and sorting in front of the first atomic - and walks it.
+#define REC_META 4                                   // words behind the LDS image: [0] = swap | valid << 1
+template <bool RENDER, int DBG, int NT, int PHASE>
 __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes, const Bound bnd,
                                                           const float* __restrict__ rays_o,
                                                           const float* __restrict__ rays_d,
                                                           const float* __restrict__ z_vals,     // RENDER ? [R,S] : pts [N,3]
                                                           const int* __restrict__ perm, int R, int S,
                                                           const float* __restrict__ g_feat, int bundle,
-                                                          int allow_counting, int nbundles, int xcd_map) {
+                                                          int allow_counting, int nbundles, int xcd_map,
+                                                          unsigned* __restrict__ records) {
     constexpr int dbg_mode = DBG;
     constexpr int BM = 4 * NT;
     constexpr int SLOT_BITS = (BM == 1024) ? 10 : 11;
@@ -317,6 +324,16 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
     const int nu = min(bundle, nunits - u0);
     const int n = nu * per;                                           // <= BM by construction of `bundle`
 
+    unsigned* const rimg = (PHASE != 0) ? records + ((size_t)bidx * NPL + pi) * (6 * BM + REC_META) : nullptr;
+    bool swap = false;
+    if (PHASE == 2) {
+        // the sorted record image of this (bundle, plane), as eslam_scatter_prep left it
+        const unsigned meta = rimg[6 * BM];
+        if (!(meta & 2u)) return;                                         // no valid sample in this bundle
+        swap = (meta & 1u) != 0;
+        for (int i = threadIdx.x; i < 6 * BM / 4; i += NT) ((uint4*)lds_raw)[i] = ((const uint4*)rimg)[i];
+        __syncthreads();
+    } else {
     if (threadIdx.x == 0) { sbox[0] = 0x7FFFFFFF; sbox[1] = -1; sbox[2] = 0x7FFFFFFF; sbox[3] = -1; }
     __syncthreads();
 
@@ -367,8 +384,11 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
     // of the sorted list are neighbours along it and share a texel column that is carried instead of flushed twice.
     const int bxmin = sbox[0], bxmax = sbox[1], bymin = sbox[2], bymax = sbox[3];
     __syncthreads();                                                  // sbox's memory is reused from here on
-    if (bxmax < 0) return;                                            // no valid sample in this bundle
-    const bool swap = (bymax - bymin) > (bxmax - bxmin);              // travels along y: column-major keys
+    if (bxmax < 0) {                                                  // no valid sample in this bundle
+        if (PHASE == 1 && threadIdx.x == 0) rimg[6 * BM] = 0u;
+        return;
+    }
+    swap = (bymax - bymin) > (bxmax - bxmin);                         // travels along y: column-major keys
     // Bundles whose cells fit a small box (the normal case: 32 neighbouring rays) are ordered by a counting sort over
     // the box - one LDS integer atomic per sample, one scan, one placement pass - instead of the 66-stage bitonic
     // network (50 us of this kernel's 165).  Rows of the box get one padding column so that "next cell along the minor
@@ -522,6 +542,12 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
     }
     __syncthreads();
     }
+    if (PHASE == 1) {
+        for (int i = threadIdx.x; i < 6 * BM / 4; i += NT) ((uint4*)rimg)[i] = ((const uint4*)lds_raw)[i];
+        if (threadIdx.x == 0) rimg[6 * BM] = (swap ? 1u : 0u) | 2u;
+        return;
+    }
+    }       // PHASE != 2
     if (dbg_mode == 2) return;
 
     // (3) walk: wave w owns sorted entries [256w, 256w+256), 64 at a time.  Per 64-entry block every lane fetches ONE
@@ -746,9 +772,25 @@ extern "C" int eslam_ray_order(const float* rays_o, const float* rays_d, int R, 
 }
 
 // perm: ray order to bundle by (render mode), or NULL for the given order
+static int scatter_bundle_size(int S, bool render, int* bm_out) {
+    static const int bm = env_int("ESLAM_SC_BUNDLE", 2048);        // profiling switch: 1024 or 2048
+    *bm_out = bm == 1024 ? 1024 : 2048;
+    return *bm_out / (render ? S : 64);
+}
+
+// bytes of the record images eslam_scatter_prep writes for R rays x S samples
+extern "C" int64_t eslam_scatter_records_bytes(int R, int S) {
+    if (R <= 0 || S <= 0 || S > ESLAM_MAX_SAMPLES) return -1;
+    int bm;
+    const int bundle = scatter_bundle_size(S, true, &bm);
+    const int64_t nbundles = (R + bundle - 1) / bundle;
+    return nbundles * NPL * (6 * (int64_t)bm + REC_META) * 4;
+}
+
+// phase 0: cells + sort + walk; 1: cells + sort -> records (g_feat unused); 2: walk of the records
 int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float* rays_o, const float* rays_d,
                      const float* z_or_pts, int64_t R, int S, bool render, const float* g_feat, const int* perm,
-                     hipStream_t st) {
+                     hipStream_t st, unsigned* records, int phase) {
     PlaneSet ps;
     for (int i = 0; i < NPL; ++i) {
         ps.p[i] = planes[i];
@@ -774,31 +816,59 @@ int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float*
     if (nosort) perm = nullptr;
     const int per = render ? S : 64;
     // 2048 samples per workgroup (512 threads) halve the number of cell flushes of 1024; S up to 256 -> >= 8 rays
-    static const int bm = env_int("ESLAM_SC_BUNDLE", 2048);        // profiling switch: 1024 or 2048
+    int bm;
+    const int bundle = scatter_bundle_size(per, render, &bm);
     for (int i = 0; i < NPL; ++i)
         if ((int64_t)planes[i].w * planes[i].h >= ((1 << 21) - 2)) {
             eslam_set_error("scatter: plane %d has %d x %d cells, limit 2^21", i, planes[i].h, planes[i].w);
             return 1;
         }
     static const int counting = env_int("ESLAM_SC_COUNTING", 1);   // A/B switch: 0 = always the bitonic network
-    const int bundle = (bm == 1024 ? 1024 : 2048) / per;
     static const int xcd_map = env_int("ESLAM_SC_XCDMAP", 1);      // A/B switch: 0 = plain (bundle, plane) grid
     const int nbundles = (nunits + bundle - 1) / bundle;
     dim3 grid(nbundles, NPL);
     if (xcd_map) grid = dim3(((nbundles * 4 + 7) / 8) * 8 * 3, 1);
-#define LAUNCH_SC(RD, DB, NTv, PERM, SS)                                                                               \
-    hipLaunchKernelGGL((scatter_sort_kernel<RD, DB, NTv>), grid, dim3(NTv), 0, st, ps, bnd, rays_o, rays_d, z_or_pts, \
-                       PERM, (int)R, SS, g_feat, bundle, counting, nbundles, xcd_map)
+#define LAUNCH_SC(RD, DB, NTv, PH, PERM, SS)                                                                               \
+    hipLaunchKernelGGL((scatter_sort_kernel<RD, DB, NTv, PH>), grid, dim3(NTv), 0, st, ps, bnd, rays_o, rays_d, z_or_pts, \
+                       PERM, (int)R, SS, g_feat, bundle, counting, nbundles, xcd_map, records)
+    if (phase != 0 && (!render || !records)) {
+        eslam_set_error("scatter: record phases need render mode and a record buffer");
+        return 1;
+    }
     if (render) {
-        if (dbg_mode == 1) LAUNCH_SC(true, 1, 512, perm, S);
-        else if (dbg_mode == 2) LAUNCH_SC(true, 2, 512, perm, S);
-        else if (bm == 1024) LAUNCH_SC(true, 0, 256, perm, S);
-        else LAUNCH_SC(true, 0, 512, perm, S);
+        if (phase == 1) { if (bm == 1024) LAUNCH_SC(true, 0, 256, 1, perm, S); else LAUNCH_SC(true, 0, 512, 1, perm, S); }
+        else if (phase == 2) { if (bm == 1024) LAUNCH_SC(true, 0, 256, 2, perm, S); else LAUNCH_SC(true, 0, 512, 2, perm, S); }
+        else if (dbg_mode == 1) LAUNCH_SC(true, 1, 512, 0, perm, S);
+        else if (dbg_mode == 2) LAUNCH_SC(true, 2, 512, 0, perm, S);
+        else if (bm == 1024) LAUNCH_SC(true, 0, 256, 0, perm, S);
+        else LAUNCH_SC(true, 0, 512, 0, perm, S);
     } else {
-        LAUNCH_SC(false, 0, 512, (const int*)nullptr, 64);
+        LAUNCH_SC(false, 0, 512, 0, (const int*)nullptr, 64);
     }
 #undef LAUNCH_SC
     return eslam_check_launch("scatter_sort_kernel");
+}
+
+bool eslam_planes_channels_last(const eslam_plane_t* planes, int first, int count);
+int eslam_validate_planes(const eslam_plane_t* planes, int first, int count);
+
+extern "C" int eslam_scatter_prep(const eslam_plane_t* planes, const float* bound6_host, const float* rays_o,
+                                  const float* rays_d, const float* z_vals, int R, int S, const int32_t* ray_order,
+                                  void* records, eslam_stream_t stream) {
+    if (R <= 0) return 0;
+    if (S <= 0 || S > ESLAM_MAX_SAMPLES) {
+        eslam_set_error("eslam_scatter_prep: S=%d outside [1,%d]", S, ESLAM_MAX_SAMPLES);
+        return 1;
+    }
+    if (!planes || !bound6_host || !rays_o || !rays_d || !z_vals || !ray_order || !records) {
+        eslam_set_error("eslam_scatter_prep: null argument");
+        return 1;
+    }
+    if (eslam_validate_planes(planes, 0, NPL)) return 1;
+    Bound bnd;
+    for (int k = 0; k < 3; ++k) { bnd.lo[k] = bound6_host[2 * k]; bnd.hi[k] = bound6_host[2 * k + 1]; }
+    return eslam_scatter_v2(planes, bnd, rays_o, rays_d, z_vals, R, S, true, nullptr, (const int*)ray_order,
+                            (hipStream_t)stream, (unsigned*)records, 1);
 }
 
 int eslam_scatter_v2_init() {

@@ -142,6 +142,9 @@ def ray_order_async(rays_o, rays_d):
         _hip.check(_hip.lib().eslam_ray_order(_hip.ptr(ro), _hip.ptr(rd), R, _hip.ptr(perm),
                                               ctypes.c_void_p(side.cuda_stream)), "eslam_ray_order")
     perm.record_stream(side)
+    for t, src in ((ro, rays_o), (rd, rays_d)):
+        if t.data_ptr() != src.data_ptr():
+            t.record_stream(side)        # a contiguous copy made on the current stream and read on the side stream
     return perm, side
 
 
@@ -149,6 +152,15 @@ def ray_order_async(rays_o, rays_d):
 # MI355X it is faster on the rays as given (119 vs 123-125 us at 4096x64 - sorted neighbours hit the same L2 channels).
 _FWD_USES_ORDER = os.environ.get("ESLAM_FWD_ORDER", "0") == "1"
 
+
+# ESLAM_SCATTER_SPLIT=1: the first half of the plane-gradient scatter (eslam_scatter_prep: cells + per-bundle sort, a
+# function of the sample positions only) runs on the ray-order side stream beside the forward kernel and the backward only
+# walks the sorted records.  OFF by default: measured on MI355X the walk-only kernel takes as long as the whole fused
+# kernel (121 vs 115 us at 4096 x 64 - with every workgroup walking at once the walk is bound by the feature-gradient
+# loads and the atomics, which the staggered phases of the fused kernel overlap with other workgroups' sorts), the 75 MB
+# of records cost their own traffic, and a replayed graph gains nothing from the side-stream branch: 0.369 vs 0.323 ms
+# per step.  Only launch-latency-bound batches profit in the kernel itself (200 x 32: 36 vs 51 us).  profiles/r02/.
+_SCATTER_SPLIT = os.environ.get("ESLAM_SCATTER_SPLIT", "0") == "1"
 
 _fused_loss = None
 
@@ -264,6 +276,21 @@ class RenderFn(torch.autograd.Function):
         fl = lossctx
         ctx.set_materialize_grads(False)
         ctx.lossctx = None
+        records = None
+        if (_SCATTER_SPLIT and needs and order_in is not None and not _FWD_USES_ORDER and
+                any(ctx.needs_input_grad[RenderFn.N_LEAD:RenderFn.N_LEAD + 12])):
+            # first half of the backward's scatter (cells + per-bundle sort: a function of the sample positions only) on
+            # the ray-order side stream, beside the forward kernel; joined in the backward with the order itself
+            nbytes = lib.eslam_scatter_records_bytes(R, S)
+            records = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))          # z_vals come from the samplers on this stream
+            with _hip.on_device(dev), torch.cuda.stream(side):
+                _hip.check(lib.eslam_scatter_prep(arr, _hip.make_bound(bound6), _hip.ptr(rays_o), _hip.ptr(rays_d),
+                                                  _hip.ptr(z_vals), R, S, _hip.ptr(order), _hip.ptr(records),
+                                                  ctypes.c_void_p(side.cuda_stream)), "eslam_scatter_prep")
+            records.record_stream(side)
+            for t in (rays_o, rays_d, z_vals):
+                t.record_stream(side)
         with _hip.on_device(dev):
             if fl is None:
                 _hip.check(lib.eslam_render_fwd(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(rays_o),
@@ -290,12 +317,16 @@ class RenderFn(torch.autograd.Function):
                                                      _hip.ptr(_loss_scratch(dev)), _hip.ptr(fl.acc), _hip.ptr(fl.value),
                                                      _take_rng_bump(dev), _hip.stream_handle(dev)), "eslam_render_fwd_loss")
                 ctx.lossctx = st
+        if order_in is not None and side is not None:
+            # join the side stream (ray order, scatter records) BEHIND the forward kernel: the work beside it has overlapped,
+            # and no fork is left dangling if this forward is never followed by a backward (or sits in a graph of its own)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            side = None
         if needs:
             ctx.bound6 = bound6
-            ctx.order_stream = side if order_in is not None else None
+            ctx.order_stream = None
+            ctx.records = records
             ctx.save_for_backward(rays_o, rays_d, z_vals, sdf, raw_rgb, feat, order, beta, depth, rgb, *planes, *params)
-        elif order_in is not None and not _FWD_USES_ORDER:
-            torch.cuda.current_stream(dev).wait_stream(side)      # nobody will join it later
         if fl is not None:
             return depth, rgb, sdf, fl.value.detach()     # an alias: the state must not hold the output object itself
         return depth, rgb, sdf
@@ -339,6 +370,8 @@ class RenderFn(torch.autograd.Function):
         ws = torch.empty(lib.eslam_bwd_workspace_bytes(R * S), dtype=torch.uint8, device=dev)
         g_depth, g_rgb, g_sdf = _c(g_depth), _c(g_rgb), _c(g_sdf)
         fl = ctx.lossctx                 # a _LossState
+        records = getattr(ctx, "records", None)
+        ctx.records = None
         with _hip.on_device(dev):
             if fl is not None and g_loss is not None:
                 # the loss's gradients are formed inside the backward kernel from the set sizes in acc (a ray-sharded caller
@@ -351,13 +384,13 @@ class RenderFn(torch.autograd.Function):
                     _hip.ptr(fl.gt_depth), _hip.ptr(fl.gt_color), fl.truncation, w5, _hip.ptr(fl.ray_mask),
                     _hip.ptr(fl.acc if fl.acc_global is None else fl.acc_global), _hip.ptr(up), _hip.ptr(fl.value) if fl.rewrite_value else None, _hip.ptr(g_depth),
                     _hip.ptr(g_rgb), _hip.ptr(g_sdf), _hip.ptr(g_dec), _hip.ptr(g_beta), _hip.ptr(g_ro), _hip.ptr(g_rd),
-                    _hip.ptr(order), _hip.ptr(ws), _hip.stream_handle(dev)), "eslam_render_bwd_loss")
+                    _hip.ptr(order), _hip.ptr(records), _hip.ptr(ws), _hip.stream_handle(dev)), "eslam_render_bwd_loss")
             else:
                 _hip.check(lib.eslam_render_bwd(arr, ctypes.byref(dec), _hip.make_bound(ctx.bound6), _hip.ptr(rays_o),
                                                 _hip.ptr(rays_d), _hip.ptr(z_vals), R, S, _hip.ptr(sdf), _hip.ptr(raw_rgb),
                                                 _hip.ptr(feat), _hip.ptr(g_depth), _hip.ptr(g_rgb), _hip.ptr(g_sdf),
                                                 _hip.ptr(g_dec), _hip.ptr(g_beta), _hip.ptr(g_ro), _hip.ptr(g_rd),
-                                                _hip.ptr(order), _hip.ptr(ws), _hip.stream_handle(dev)),
+                                                _hip.ptr(order), _hip.ptr(records), _hip.ptr(ws), _hip.stream_handle(dev)),
                            "eslam_render_bwd")
         if sink is not None:
             # the data-parallel caller owns .grad assignment (FlatGrads.assign): hand autograd nothing to accumulate

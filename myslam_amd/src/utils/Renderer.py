@@ -64,8 +64,9 @@ class Renderer(object):
         """Renderer.py:149-153 (kept for callers; the kernels fuse it)."""
         return 1. - torch.exp(-beta * torch.sigmoid(-sdf * beta))
 
-    def render_img(self, all_planes, decoders, c2w, truncation, device, gt_depth=None):
-        """Renderer.py:155-204: all H*W rays in chunks of ray_batch_size, no grad; depth returned as float64."""
+    def render_img(self, all_planes, decoders, c2w, truncation, device, gt_depth=None, _rand_chunks=None):
+        """Renderer.py:155-204: all H*W rays in chunks of ray_batch_size, no grad; depth returned as float64.
+        `_rand_chunks` (tests only): per chunk the three uniform tensors to inject instead of drawing them."""
         with torch.no_grad():
             H, W = self.H, self.W
             rays_o, rays_d = get_rays(H, W, self.fx, self.fy, self.cx, self.cy, c2w, device)
@@ -73,10 +74,11 @@ class Renderer(object):
             rays_d = rays_d.reshape(-1, 3)
             gt_depth = gt_depth.reshape(-1)
             depth_list, color_list = [], []
-            for i in range(0, rays_d.shape[0], self.ray_batch_size):
+            for k, i in enumerate(range(0, rays_d.shape[0], self.ray_batch_size)):
                 ret = self.render_batch_ray(all_planes, decoders, rays_d[i:i + self.ray_batch_size],
                                             rays_o[i:i + self.ray_batch_size], device, truncation,
-                                            gt_depth=gt_depth[i:i + self.ray_batch_size])
+                                            gt_depth=gt_depth[i:i + self.ray_batch_size],
+                                            _rand=None if _rand_chunks is None else _rand_chunks[k])
                 depth_list.append(ret[0].double())
                 color_list.append(ret[1])
             return torch.cat(depth_list, 0).reshape(H, W), torch.cat(color_list, 0).reshape(H, W, 3)

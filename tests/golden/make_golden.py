@@ -290,6 +290,36 @@ def decoder_case(ref, name="decoders_room0_points"):
     print(name, "ok")
 
 
+def render_img_case(ref, name="render_img_room0_30x44"):
+    """Renderer.render_img (src/utils/Renderer.py:155-204) on a small image: three chunks of the reference's ray batching
+    with a ragged last one, 5 % of the pixels without depth (importance branch), perturbation on, a rotated camera.
+    Outputs stored in full: depth [H,W] float64, colour [H,W,3]."""
+    cfg, ns, sc = ref_setup(ref, "room0")
+    H, W = 30, 44
+    ns.H, ns.W, ns.fx, ns.fy, ns.cx, ns.cy = H, W, 22.0, 22.0, (W - 1) / 2, (H - 1) / 2
+    cfg["rendering"]["perturb"] = True
+    renderer = ref.Renderer(cfg, ns, ray_batch_size=500)
+    renderer.n_stratified, renderer.n_importance = 16, 8
+    decoders = ns.shared_decoders
+    trunc = cfg["model"]["truncation"]
+    planes = scn.synth_planes(sc, channels_last=False)
+    all_planes = tuple(list(grp) for grp in planes)
+    c2w = keyframe_poses(1, sc, stream=810)[0]
+    gt_depth = torch.from_numpy(synth.depth_image(H, W, 820, 0.05))
+    with HashRNG(830) as rng:
+        depth, color = renderer.render_img(all_planes, decoders, c2w, trunc, "cpu", gt_depth=gt_depth)
+    assert depth.dtype == torch.float64 and tuple(depth.shape) == (H, W) and tuple(color.shape) == (H, W, 3)
+    fx = dict(H=np.int64(H), W=np.int64(W), fx=np.float64(ns.fx), fy=np.float64(ns.fy), cx=np.float64(ns.cx),
+              cy=np.float64(ns.cy), ray_batch_size=np.int64(500), n_stratified=np.int64(16), n_importance=np.int64(8),
+              truncation=np.float64(trunc), c2w=c2w.numpy(), depth_stream=np.int64(820), zero_frac=np.float64(0.05),
+              rand_calls=rng.calls_array(), depth=depth.numpy(), color=color.numpy(),
+              n_zero=np.int64(int((gt_depth == 0).sum())))
+    for k, v in param_dict(decoders).items():
+        fx["param:" + k] = v
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
+    print(name, "ok: zero-depth pixels", int((gt_depth == 0).sum()), "rand calls", len(rng.calls))
+
+
 def keyframe_poses(K, sc, stream=700):
     """K camera poses inside the scene: yaw angles all round the compass (so some views overlap the current frame and
     some look away), small pitch, translation within 1 m of the AABB centre.  Shared by the fixture and the tests."""
@@ -347,6 +377,8 @@ def main():
         decoder_case(ref)
     if want("keyframe_overlap"):
         keyframe_overlap_case(ref)
+    if want("render_img"):
+        render_img_case(ref)
     # BASELINE.json configs[0]: 200 rays x 32 samples (24+8), CPU plumbing case - stored in full
     if want("room0_200x32"):
         render_case(ref, "room0_200x32", "room0", 200, 24, 8, 0.0)

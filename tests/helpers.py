@@ -38,21 +38,27 @@ def rand_inputs(fx):
     """
     calls = [c.split(";") for c in fx["rand_calls"].tolist()]
     rands = [c for c in calls if c[0] == "rand"]
-    gt_depth = fx["gt_depth"]
-    has = gt_depth > 0
-    R = gt_depth.shape[0]
-    ns, ni = int(fx["n_stratified"]), int(fx["n_importance"])
+    out, k = rand_inputs_from(rands, fx["gt_depth"], int(fx["n_stratified"]), int(fx["n_importance"]), bool(fx["perturb"]))
+    assert k == len(rands)
+    return out
+
+
+def rand_inputs_from(rands, gt_depth, ns, ni, perturb):
+    """The (t_rand, t_uni, u) of ONE render_batch_ray call from the head of `rands` (a list of recorded rand calls);
+    returns them and the number of calls consumed."""
+    has = np.asarray(gt_depth) > 0
+    R = has.shape[0]
     S = ns + ni
     t_rand = t_uni = u = None
     k = 0
-    if bool(fx["perturb"]):
+    if perturb:
         c = rands[k]; k += 1
         assert (int(c[2]), int(c[3])) == (int(has.sum()), S), c
         t_rand = np.zeros((R, S), np.float32)
         t_rand[has] = synth.hash_uniform((int(c[2]), int(c[3])), int(c[1]))
     if not has.all():
         R0 = int((~has).sum())
-        if bool(fx["perturb"]):
+        if perturb:
             c = rands[k]; k += 1
             assert (int(c[2]), int(c[3])) == (R0, ns), c
             t_uni = np.zeros((R, ns), np.float32)
@@ -61,9 +67,31 @@ def rand_inputs(fx):
         assert (int(c[2]), int(c[3])) == (R0, ni), c
         u = np.zeros((R, ni), np.float32)
         u[~has] = synth.hash_uniform((R0, ni), int(c[1]))
-    assert k == len(rands)
     cv = lambda a: None if a is None else torch.from_numpy(a)
-    return cv(t_rand), cv(t_uni), cv(u)
+    return (cv(t_rand), cv(t_uni), cv(u)), k
+
+
+def render_img_chunk_rands(fx, gt_depth_flat):
+    """Per chunk of Renderer.render_img (ray_batch_size rays each) the random tensors the reference drew for it."""
+    rands = [c.split(";") for c in fx["rand_calls"].tolist()]
+    bs, ns, ni = int(fx["ray_batch_size"]), int(fx["n_stratified"]), int(fx["n_importance"])
+    out = []
+    for i in range(0, gt_depth_flat.shape[0], bs):
+        r, k = rand_inputs_from(rands, gt_depth_flat[i:i + bs], ns, ni, True)
+        rands = rands[k:]
+        out.append(r)
+    assert not rands
+    return out
+
+
+def elementwise_close(a, b, rtol=1e-4, floor=1e-6):
+    """|a - b| <= rtol |b| + floor max|b| for EVERY element (north_star: 1e-4 relative; the floor keeps elements that are
+    near zero against the tensor's scale - an sdf crossing zero, a dim colour channel - from demanding absolute 1e-10)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    tol = rtol * np.abs(b) + floor * (np.abs(b).max() + 1e-30)
+    bad = np.abs(a - b) > tol
+    return not bad.any(), (int(bad.sum()), float((np.abs(a - b) / tol).max()))
 
 
 def scene_and_planes(fx, device="cpu", dtype=torch.float32, channels_last=True, requires_grad=False):

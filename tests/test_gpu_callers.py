@@ -307,3 +307,29 @@ def test_in_kernel_jitter_is_uniform_fresh_per_step_and_reproducible():
     assert abs(float((a * b).mean()) * 12) < 0.03
     a, b = tt[:-1, 2:20].reshape(-1) - 0.5, tt[1:, 2:20].reshape(-1) - 0.5
     assert abs(float((a * b).mean()) * 12) < 0.03
+
+
+def test_integration_md_ctypes_snippet_runs_as_written():
+    """INTEGRATION.md section 3 shows a raw ctypes call of eslam_render_fwd: execute that code block LITERALLY (VERDICT r01:
+    the snippet had lost an argument) and compare with the shipped binding."""
+    import os
+    import re
+    from myslam_amd import harness, ops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    m = re.search(r"```python\n(# \(tests/test_gpu_callers.py::test_integration_md_ctypes_snippet_runs_as_written.*?)```", md, re.S)
+    assert m, "the section-3 snippet is gone from INTEGRATION.md"
+    code = m.group(1).replace('ctypes.CDLL("myslam_amd/lib/libeslam_hip.so")',
+                              f'ctypes.CDLL("{os.path.join(root, "myslam_amd", "lib", "libeslam_hip.so")}")')
+    dev = torch.device("cuda:0")
+    wl = harness.make_workload("room0", 300, 24, 8, device=dev)
+    with torch.no_grad():
+        d_ref, c_ref, s_ref, z = wl.renderer.render_batch_ray(wl.planes, wl.decoders, wl.rays_d, wl.rays_o, dev, wl.truncation,
+                                                              gt_depth=wl.gt_depth)
+    b = ops.bound_to_host(wl.decoders.bound)
+    env = dict(all_planes=wl.planes, decoder_tensors_in_header_order=[p.detach() for p in ops.decoder_params(wl.decoders)],
+               beta_tensor=wl.decoders.beta.detach(), x0=b[0], x1=b[1], y0=b[2], y1=b[3], z0=b[4], z1=b[5],
+               rays_o=wl.rays_o.detach(), rays_d=wl.rays_d.detach(), z_vals=z.contiguous())
+    exec(compile(code, "INTEGRATION.md section 3", "exec"), env)
+    torch.cuda.synchronize()
+    assert torch.equal(env["depth"], d_ref) and torch.equal(env["rgb"], c_ref) and torch.equal(env["sdf"], s_ref)

@@ -137,3 +137,34 @@ def test_grid_sample_variant_of_the_oracle_matches_too(monkeypatch):
         assert hp.rel_err(p.grad.numpy(), fx["grad:" + k]) <= GRAD_RTOL, k
     assert hp.rel_err(r["rd"].grad.numpy()[pr], fx["g_rays_d"]) <= GRAD_RTOL
     hp.check_plane_probes(fx, [p.grad for p in hp.flat_planes(r["planes"])], rtol=GRAD_RTOL)
+
+
+def test_render_img_matches_reference():
+    """Renderer.render_img (src/utils/Renderer.py:155-204) restated with the oracle's pieces: full-image rays, the
+    reference's ray batching (ragged last chunk), depth as float64."""
+    fx = hp.load("render_img_room0_30x44")
+    from myslam_amd import scene as scn, synth
+    sc = scn.make_scene("room0")
+    planes = scn.synth_planes(sc, channels_last=False)
+    params = hp.params_from(fx)
+    H, W = int(fx["H"]), int(fx["W"])
+    ro, rd = orc.rays_full_image(H, W, float(fx["fx"]), float(fx["fy"]), float(fx["cx"]), float(fx["cy"]),
+                                 torch.from_numpy(fx["c2w"]))
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    gd = torch.from_numpy(synth.depth_image(H, W, int(fx["depth_stream"]), float(fx["zero_frac"]))).reshape(-1)
+    assert int((gd == 0).sum()) == int(fx["n_zero"]) > 0
+    rands = hp.render_img_chunk_rands(fx, gd.numpy())
+    bs, ns, ni = int(fx["ray_batch_size"]), int(fx["n_stratified"]), int(fx["n_importance"])
+    assert len(rands) == 3 and (H * W) % bs != 0
+    depth, color = [], []
+    with torch.no_grad():
+        for k, i in enumerate(range(0, H * W, bs)):
+            d, c, _, _ = orc.render_batch_ray(planes, params, 10.0, sc.bound, rd[i:i + bs], ro[i:i + bs], float(fx["truncation"]),
+                                              gd[i:i + bs], ns, ni, *rands[k])
+            depth.append(d.double())
+            color.append(c)
+    depth, color = torch.cat(depth).reshape(H, W), torch.cat(color).reshape(H, W, 3)
+    assert hp.rel_err(depth.numpy(), fx["depth"]) <= OUT_RTOL
+    assert hp.rel_err(color.numpy(), fx["color"]) <= OUT_RTOL
+    ok, info = hp.elementwise_close(depth.numpy(), fx["depth"], rtol=1e-4)
+    assert ok, info
