@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ESLAM_ABI_VERSION 2
+#define ESLAM_ABI_VERSION 3
 #define ESLAM_C_DIM 32          /* feature channels per plane (configs/ESLAM.yaml:77)               */
 #define ESLAM_HIDDEN 16         /* decoder hidden width (src/networks/decoders.py:39)               */
 #define ESLAM_FEAT (2 * ESLAM_C_DIM)   /* coarse || fine                                          */
@@ -44,6 +44,11 @@ typedef struct {
     float* grad;            /* same strides as data; kernels ACCUMULATE (+=) into it; may be NULL  */
     int32_t h, w;
     int64_t stride_c, stride_y, stride_x;   /* in elements                                         */
+    const void* data_f16;   /* optional IEEE-half copy of the plane, channels-last with the SAME element strides
+                               (stride_c = 1, stride_x = 32: 64-byte texels).  When all 12 planes carry one, eslam_render_fwd*,
+                               eslam_render_bwd* run the mixed-precision path of BASELINE.json configs[4]: texels gathered from
+                               the half copies (float32 accumulation), decoders on bf16 MFMA forward AND backward, plane
+                               gradients accumulated in float32 into `grad` (the float32 master's gradient).        */
 } eslam_plane_t;
 
 typedef struct {            /* src/networks/decoders.py:47-60                                      */
@@ -144,10 +149,16 @@ int eslam_render_fwd_loss(const eslam_plane_t* planes, const eslam_decoders_t* d
                           const uint8_t* ray_mask, float* scratch, float* acc, float* loss, uint32_t* rng_bump,
                           eslam_stream_t stream);
 
+/* Refresh the half copies of all 12 planes from their float32 masters (both channels-last), one launch: what a
+ * mixed-precision training loop runs after every optimiser step.                                            */
+int eslam_planes_to_half(const eslam_plane_t* planes, eslam_stream_t stream);
+
 /* Mixed-precision forward for inference (BASELINE.json configs[4], a tolerance study): planes_f16[i].data points to
  * IEEE-half data of a channels-last [1,32,h,w] plane (strides in half elements: stride_c = 1, stride_x = 32), the decoder
  * weights are rounded to bf16 inside the kernel and run on bf16 MFMA with float32 accumulation; everything after the MLPs
- * (activations, alpha, transmittance, composite) is float32.  Same outputs as eslam_render_fwd; no backward.        */
+ * (activations, alpha, transmittance, composite) is float32.  Same outputs as eslam_render_fwd.  (Round-1 entry point:
+ * the general way is a `data_f16` pointer in every eslam_plane_t, which switches eslam_render_fwd / _fwd_loss / _bwd /
+ * _bwd_loss to the mixed-precision kernels, backward included.)                                                   */
 int eslam_render_fwd_lowp(const eslam_plane_t* planes_f16, const eslam_decoders_t* dec, const float* bound6_host,
                           const float* rays_o, const float* rays_d, const float* z_vals, int R, int S, float* depth,
                           float* rgb, float* sdf, eslam_stream_t stream);
@@ -316,6 +327,14 @@ int eslam_keep_best(const float* loss, const float* pose, int n, float* best, fl
  * when allocating them and then only hands to this function (it holds a self-resetting ticket counter and the
  * running sums, one cache line each; one scratch per concurrently running stream).  eslam_loss_grad(acc) gives the gradients. */
 #define ESLAM_LOSS_SCRATCH (32 * 17)
+/* Size (floats) of the scratch for a batch of n_rays: ESLAM_LOSS_SCRATCH, or more in deterministic mode.
+ * eslam_deterministic(): 1 when the process runs with ESLAM_DETERMINISTIC=1 - the loss's sums are then reduced in a fixed
+ * order (per-workgroup slots instead of float atomics) and the plane-gradient scatter accumulates in 64-bit fixed point
+ * (integer adds commute), so every output of the path is bitwise reproducible from run to run, at a lower speed.
+ * eslam_loss_scratch_reset: back to the freshly-zeroed state, e.g. after a graph was aborted mid-flight.             */
+int eslam_deterministic(void);
+int64_t eslam_loss_scratch_floats(int64_t n_rays);
+int eslam_loss_scratch_reset(float* scratch, int64_t floats, eslam_stream_t stream);
 int eslam_loss_value(const float* depth, const float* rgb, const float* sdf, const float* z_vals,
                      const float* gt_depth, const float* gt_color, int R, int S, double truncation,
                      const float* weights5_host, const uint8_t* ray_mask, float* scratch, float* acc, float* loss,

@@ -14,14 +14,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ESLAM_HIP_LIB: another build of the SAME library (A/B of compile-time kernel variants, tools/ab_variants.py); never a fallback
 LIB_PATH = os.environ.get("ESLAM_HIP_LIB") or os.path.join(_HERE, "lib", "libeslam_hip.so")
 
-ABI_VERSION = 2              # ESLAM_ABI_VERSION
+ABI_VERSION = 3              # ESLAM_ABI_VERSION
 N_DEC_PARAMS = 2692
 N_PLANES = 12
 
 
 class PlaneDesc(ctypes.Structure):
     _fields_ = [("data", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("h", ctypes.c_int32), ("w", ctypes.c_int32),
-                ("stride_c", ctypes.c_int64), ("stride_y", ctypes.c_int64), ("stride_x", ctypes.c_int64)]
+                ("stride_c", ctypes.c_int64), ("stride_y", ctypes.c_int64), ("stride_x", ctypes.c_int64),
+                ("data_f16", ctypes.c_void_p)]
 
 
 class DecodersDesc(ctypes.Structure):
@@ -52,6 +53,7 @@ SIGNATURES = {
     "eslam_render_fwd": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "eslam_render_fwd_loss": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _BP, _vp,
                                    _vp, _vp, _vp, _vp, _vp]),
+    "eslam_planes_to_half": (_i, [_PP, _vp]),
     "eslam_render_fwd_lowp": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "eslam_ray_order": (_i, [_vp, _vp, _i, _vp, _vp]),
     "eslam_bwd_workspace_bytes": (_i64, [_i64]),
@@ -69,6 +71,9 @@ SIGNATURES = {
     "eslam_profile_read": (_i, [_BP]),
     "eslam_profile_name": (ctypes.c_char_p, [_i]),
     "eslam_loss_grad": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _BP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "eslam_deterministic": (_i, []),
+    "eslam_loss_scratch_floats": (_i64, [_i64]),
+    "eslam_loss_scratch_reset": (_i, [_vp, _i64, _vp]),
     "eslam_loss_value": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _BP, _vp, _vp, _vp, _vp, _vp]),
     "eslam_adam_step": (_i, [_vp, _i, _i, _vp, _d, _d, _d, _i, _vp]),
     "eslam_prefilter": (_i, [_vp, _vp, _vp, _i, _BP, _i, _vp, _vp]),
@@ -174,7 +179,7 @@ def require_gpu_f32(name, t):
 _plane_cache = {}
 
 
-def make_planes(all_planes, grads=None, dtype=torch.float32):
+def make_planes(all_planes, grads=None, dtype=torch.float32, half=None):
     """all_planes: the reference's 6-tuple of [coarse, fine] lists -> (PlaneArray, keepalive list).
 
     Descriptors are cached per (data pointers, shapes, row strides): the mapper keeps the same 12 storages for a whole
@@ -183,7 +188,9 @@ def make_planes(all_planes, grads=None, dtype=torch.float32):
     flat = [p for grp in all_planes for p in grp]
     if len(flat) != N_PLANES or any(len(grp) != 2 for grp in all_planes):
         raise RuntimeError("all_planes must be 6 groups of [coarse, fine] planes")
-    key = (dtype,) + tuple((p.data_ptr(), p.shape[2], p.shape[3], p.stride(2)) for p in flat)
+    # the key carries everything the validation below looks at: an address reused by a different tensor (other dtype, shape,
+    # channel stride, device) misses the cache and is validated afresh
+    key = (dtype,) + tuple((p.data_ptr(), p.dtype, p.device.index, tuple(p.shape), p.stride()) for p in flat)
     hit = _plane_cache.get(key)
     if hit is None:
         arr = PlaneArray()
@@ -204,6 +211,14 @@ def make_planes(all_planes, grads=None, dtype=torch.float32):
             _plane_cache.clear()
         hit = _plane_cache[key] = (bytes(arr), [tuple(p.shape) for p in flat], [p.stride() for p in flat])
     arr = PlaneArray.from_buffer_copy(hit[0])
+    if half is not None:
+        # mixed precision: half copies of the planes, channels-last like their float32 masters (eslam_plane_t.data_f16)
+        for k, (hp, p) in enumerate(zip(half, flat)):
+            if (hp.dtype != torch.float16 or not hp.is_cuda or hp.shape != p.shape or hp.stride() != p.stride()
+                    or not p.is_contiguous(memory_format=torch.channels_last)):
+                raise RuntimeError("mixed precision: every plane needs a float16 channels_last copy of its own shape, and the "
+                                   "float32 planes must be channels_last too")
+            arr[k].data_f16 = hp.data_ptr()
     if grads is not None:
         for k, gr in enumerate(grads):
             if gr.shape != hit[1][k] or gr.stride() != hit[2][k]:
@@ -225,7 +240,8 @@ _dec_cache = {}
 
 def make_decoders(params, beta):
     """params: 12 tensors in DEC_FIELDS order; beta: device tensor [1].  Cached per set of data pointers."""
-    key = tuple(t.data_ptr() for t in params) + (beta.data_ptr(),)
+    key = tuple((t.data_ptr(), t.dtype, t.device.index, tuple(t.shape), t.stride()) for t in params) + \
+        ((beta.data_ptr(), beta.dtype, beta.device.index),)
     d = _dec_cache.get(key)
     if d is None:
         d = DecodersDesc()

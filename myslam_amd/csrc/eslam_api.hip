@@ -1,6 +1,8 @@
 // Error plumbing and argument validation shared by the C-ABI entry points.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdint.h>
+#include <stdlib.h>
 #include "eslam_common.h"
 
 static thread_local char g_err[512] = "";
@@ -23,6 +25,55 @@ int eslam_check_launch(const char* what) {
 
 extern "C" const char* eslam_last_error(void) { return g_err; }
 extern "C" int eslam_abi_version(void) { return ESLAM_ABI_VERSION; }
+
+extern "C" int eslam_deterministic(void) {
+    static const int det = [] { const char* v = getenv("ESLAM_DETERMINISTIC"); return (v && v[0] && v[0] != '0') ? 1 : 0; }();
+    return det;
+}
+
+// floats of loss scratch a batch of n_rays needs: the ticket + one line per accumulator, or (deterministic mode) the ticket
+// + one 16-float slot per workgroup of the kernel that forms the sums (4 rays per workgroup in eslam_render_fwd_loss)
+extern "C" int64_t eslam_loss_scratch_floats(int64_t n_rays) {
+    if (n_rays < 0) return -1;
+    if (!eslam_deterministic()) return ESLAM_LOSS_SCRATCH;
+    const int64_t nwg = ((n_rays + 3) / 4 + 7) / 8 * 8;
+    const int64_t need = 32 + 16 * nwg;
+    return need > ESLAM_LOSS_SCRATCH ? need : ESLAM_LOSS_SCRATCH;
+}
+
+// back to the state of a freshly zeroed scratch (after an aborted graph, a failed launch, ...): first `floats` floats
+extern "C" int eslam_loss_scratch_reset(float* scratch, int64_t floats, eslam_stream_t stream) {
+    if (!scratch || floats < ESLAM_LOSS_SCRATCH) {
+        eslam_set_error("eslam_loss_scratch_reset: null scratch or fewer than ESLAM_LOSS_SCRATCH floats");
+        return 1;
+    }
+    if (hipMemsetAsync(scratch, 0, (size_t)floats * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+        eslam_set_error("eslam_loss_scratch_reset: memset failed");
+        return 2;
+    }
+    return 0;
+}
+
+// 1: all 12 planes carry a half copy (the mixed-precision path), 0: none does, -1 (error set): some do, or a copy's layout
+// cannot be the 64-byte-texel one the half gather assumes
+int eslam_planes_lowp(const eslam_plane_t* planes) {
+    int n = 0;
+    for (int i = 0; i < ESLAM_N_PLANES; ++i) n += planes[i].data_f16 != nullptr;
+    if (n == 0) return 0;
+    if (n != ESLAM_N_PLANES) {
+        eslam_set_error("mixed precision: %d of the 12 planes carry a half copy (data_f16); give all or none", n);
+        return -1;
+    }
+    for (int i = 0; i < ESLAM_N_PLANES; ++i) {
+        const eslam_plane_t& p = planes[i];
+        if (p.stride_c != 1 || p.stride_x != ESLAM_C_DIM || p.stride_y != (int64_t)ESLAM_C_DIM * p.w || ((uintptr_t)p.data_f16 & 15)) {
+            eslam_set_error("mixed precision: plane %d must be channels-last (its half copy has 64-byte texels with the same "
+                            "element strides)", i);
+            return -1;
+        }
+    }
+    return 1;
+}
 
 // A plane is "channels-last" when one texel's 32 channels are contiguous and texels along x are adjacent.
 bool eslam_planes_channels_last(const eslam_plane_t* planes, int first, int count) {

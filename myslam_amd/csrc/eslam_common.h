@@ -137,6 +137,9 @@ enum { PROF_RENDER_FWD = 0, PROF_COMPOSITE_BWD, PROF_MLP_BWD, PROF_DEC_REDUCE, P
 void eslam_prof_begin(int id, hipStream_t st);
 void eslam_prof_end(int id, hipStream_t st);
 
+// ESLAM_DETERMINISTIC=1 (read once per process): fixed-order loss reduction and fixed-point plane-gradient scatter
+extern "C" int eslam_deterministic(void);
+
 // thread-local error string shared by the API translation units
 void eslam_set_error(const char* fmt, ...);
 int eslam_check_launch(const char* what);

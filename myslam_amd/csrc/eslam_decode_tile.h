@@ -249,3 +249,131 @@ __device__ __forceinline__ void to_gather_role(float v[NREG], int lane) {
 #pragma unroll
     for (int i = 0; i < NREG; ++i) v[i] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v[i])));
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Mixed precision (BASELINE.json configs[4]: fp16 planes + bf16 MFMA decoders): the same tile with
+//   * texels read from the planes' IEEE-half copies (64-byte texels): gather-role lane (point l >> 2, piece g = l & 3) loads
+//     channels 8g..8g+7 of a corner as ONE 16-byte load, a quad of lanes one whole texel; float32 accumulation;
+//   * decoders on bf16 MFMA with float32 accumulation: layer 1 is one v_mfma_f32_16x16x32_bf16 per level (the 8 gathered
+//     channels of MFMA-role lane (r, q), rounded to bf16, ARE its B fragment: k = 8q + j), layers 2 and 3
+//     v_mfma_f32_16x16x16_bf16, whose k = 4 (l >> 4) + j order is the accumulator's row order (rows 4q + reg): each layer's
+//     accumulator feeds the next without a shuffle, as in the float32 tile.  4 MFMAs of 16 cycles per 16 points and
+//     decoder instead of 24 of 32 cycles.
+// LDS image per decoder (shorts): W1 [16][64] @0, W2 [16][16] @1024, W3pad [4][16] @1280; float biases behind both
+// decoders' shorts: b1 [16], b2 [16], b3pad [4] per decoder.
+// ---------------------------------------------------------------------------------------------------------
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef short short8_t __attribute__((ext_vector_type(8)));
+typedef short short4_t __attribute__((ext_vector_type(4)));
+#define LP_W1 0
+#define LP_W2 1024
+#define LP_W3 1280
+#define LP_SHORTS 1344
+#define LP_BIAS_FLOATS 36
+#define LP_LDS_FLOATS (LP_SHORTS + 2 * LP_BIAS_FLOATS)      // both decoders: 2 * 1344 shorts = 1344 floats, + biases
+
+__device__ __forceinline__ short f2bf(float x) {          // round-to-nearest-even float32 -> bfloat16 bits
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (short)(u >> 16);
+}
+__device__ __forceinline__ short4_t pack4(float a, float b, float c, float d) { return (short4_t){f2bf(a), f2bf(b), f2bf(c), f2bf(d)}; }
+
+__device__ __forceinline__ short* lp_weights(float* lds, int d) { return (short*)lds + d * LP_SHORTS; }
+__device__ __forceinline__ float* lp_biases(float* lds, int d) { return lds + LP_SHORTS + d * LP_BIAS_FLOATS; }
+
+__device__ __forceinline__ void stage_decoder_weights_lowp(float* lds, const eslam_decoders_t& dec, int tid, int nthreads) {
+    for (int d = 0; d < 2; ++d) {
+        const float* w1 = d ? dec.cw1 : dec.w1;
+        const float* b1 = d ? dec.cb1 : dec.b1;
+        const float* w2 = d ? dec.cw2 : dec.w2;
+        const float* b2 = d ? dec.cb2 : dec.b2;
+        const float* w3 = d ? dec.cw3 : dec.w3;
+        const float* b3 = d ? dec.cb3 : dec.b3;
+        const int nout = d ? 3 : 1;
+        short* W = lp_weights(lds, d);
+        float* B = lp_biases(lds, d);
+        for (int i = tid; i < 1024; i += nthreads) W[LP_W1 + i] = f2bf(w1[i]);
+        for (int i = tid; i < 256; i += nthreads) W[LP_W2 + i] = f2bf(w2[i]);
+        for (int i = tid; i < 64; i += nthreads) W[LP_W3 + i] = (i < nout * 16) ? f2bf(w3[i]) : (short)0;
+        for (int i = tid; i < 16; i += nthreads) { B[i] = b1[i]; B[16 + i] = b2[i]; }
+        for (int i = tid; i < 4; i += nthreads) B[32 + i] = (i < nout) ? b3[i] : 0.0f;
+    }
+}
+
+struct DecFragLP {
+    short8_t w1[2];   // W1[r][lvl*32 + 8q .. 8q+7]
+    short4_t w2, w3;  // W2[r][4q .. 4q+3], W3pad[r & 3][4q .. 4q+3]
+    float4_t b1, b2, b3;
+};
+
+__device__ __forceinline__ void load_dec_frag_lp(DecFragLP& f, const short* W, const float* B, int r, int q) {
+    f.w1[0] = *(const short8_t*)(W + LP_W1 + r * 64 + 8 * q);
+    f.w1[1] = *(const short8_t*)(W + LP_W1 + r * 64 + 32 + 8 * q);
+    f.w2 = *(const short4_t*)(W + LP_W2 + r * 16 + 4 * q);
+    f.w3 = *(const short4_t*)(W + LP_W3 + (r & 3) * 16 + 4 * q);
+    f.b1 = *(const float4_t*)(B + 4 * q);
+    f.b2 = *(const float4_t*)(B + 16 + 4 * q);
+    f.b3 = *(const float4_t*)(B + 32);
+}
+
+// feat: MFMA role, feat[lvl*8 + j] = channel 8q + j of the level.  a1 / a2: pre-activations (float32), D layout.
+__device__ __forceinline__ void mlp_hidden_lp(const DecFragLP& f, const float feat[16], float4_t& a1, float4_t& a2) {
+    a1 = f.b1;
+#pragma unroll
+    for (int lvl = 0; lvl < 2; ++lvl) {
+        short8_t bf;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bf[i] = f2bf(feat[lvl * 8 + i]);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w1[lvl], bf, a1, 0, 0, 0);
+    }
+    const short4_t h1b = pack4(fmaxf(a1[0], 0.f), fmaxf(a1[1], 0.f), fmaxf(a1[2], 0.f), fmaxf(a1[3], 0.f));
+    a2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(f.w2, h1b, f.b2, 0, 0, 0);
+}
+
+__device__ __forceinline__ void mlp_out_accum_lp(const DecFragLP& f, const float4_t& a2, int b, int r, float4_t& out) {
+    const short4_t h2b = pack4(fmaxf(a2[0], 0.f), fmaxf(a2[1], 0.f), fmaxf(a2[2], 0.f), fmaxf(a2[3], 0.f));
+    const short4_t w3 = ((r >> 2) == b) ? f.w3 : (short4_t){0, 0, 0, 0};
+    out = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w3, h2b, out, 0, 0, 0);
+}
+
+__device__ __forceinline__ void gather8_half(const eslam_plane_t& P, float u, float v, int g, float acc[8]) {
+    const AxisCoord ax = axis_coord(u, P.w);
+    const AxisCoord ay = axis_coord(v, P.h);
+    const unsigned sy = (unsigned)P.stride_y, sx = (unsigned)P.stride_x;
+    const unsigned r0 = ay.i0 * sy, r1 = ay.i1 * sy, c0 = ax.i0 * sx, c1 = ax.i1 * sx, g8 = 8u * g;
+    const _Float16* __restrict__ data = (const _Float16*)P.data_f16;
+    const half8_t t00 = *(const half8_t*)(data + r0 + c0 + g8);
+    const half8_t t01 = *(const half8_t*)(data + r0 + c1 + g8);
+    const half8_t t10 = *(const half8_t*)(data + r1 + c0 + g8);
+    const half8_t t11 = *(const half8_t*)(data + r1 + c1 + g8);
+    const float w00 = (1.0f - ax.t) * (1.0f - ay.t), w01 = ax.t * (1.0f - ay.t), w10 = (1.0f - ax.t) * ay.t, w11 = ax.t * ay.t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        acc[i] += (float)t00[i] * w00 + (float)t01[i] * w01 + (float)t10[i] * w10 + (float)t11[i] * w11;
+}
+
+// the 64 features of decoder d for the lane's gather-role point: feat[lvl*8 + i] = channel 8g + i of the level
+__device__ __forceinline__ void gather_features_half(const PlaneSet& planes, int d, float x, float y, float z, int g,
+                                                     float feat[16], int opaque0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) feat[i] = 0.0f;
+#pragma unroll
+    for (int lvl = 0; lvl < 2; ++lvl) {
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            gather8_half(planes.p[2 * (3 * d + o) + lvl + opaque0], ORIENT_U(o, x, y, z), ORIENT_V(o, x, y, z), g, feat + 8 * lvl);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// features of the mixed-precision path in feat_out [N,128]: natural channel order, lane (point, piece g) owns channels 8g..8g+7
+__device__ __forceinline__ void store_features_lp(float* feat_out, int64_t pt, int d, int g, const float feat[16]) {
+    float* dst = feat_out + pt * 128 + d * 64 + 8 * g;
+#pragma unroll
+    for (int lvl = 0; lvl < 2; ++lvl) {
+        *(float4_t*)(dst + lvl * 32) = (float4_t){feat[lvl * 8 + 0], feat[lvl * 8 + 1], feat[lvl * 8 + 2], feat[lvl * 8 + 3]};
+        *(float4_t*)(dst + lvl * 32 + 4) = (float4_t){feat[lvl * 8 + 4], feat[lvl * 8 + 5], feat[lvl * 8 + 6], feat[lvl * 8 + 7]};
+    }
+}

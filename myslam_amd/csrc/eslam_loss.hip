@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restric
                                                           const float* __restrict__ gt_color,
                                                           const uint8_t* __restrict__ ray_mask, int R, int S, const Trunc tr,
                                                           float* __restrict__ acc, float* __restrict__ scratch,
-                                                          const LossW w, float* __restrict__ loss) {
+                                                          const LossW w, float* __restrict__ loss, const int det) {
     // grid-stride over rays: the 10 accumulators share one cache line, and same-line float atomics serialise at the
     // memory side (~12 ns each), so the number of workgroups - not of rays - sets the cost of the final adds
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -54,7 +54,8 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restric
         if (threadIdx.x < A_COUNT && tot != 0.0f) atomicAdd(acc + threadIdx.x, tot);
         return;
     }
-    loss_finalize(tot, scratch, acc, w, loss);
+    if (det) loss_finalize_det(tot, scratch, acc, w, loss);
+    else loss_finalize(tot, scratch, acc, w, loss);
 }
 
 __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ depth, const float* __restrict__ rgb,
@@ -108,7 +109,7 @@ extern "C" int eslam_loss_reduce(const float* depth, const float* rgb, const flo
     }
     const int nwg = (R + 3) / 4 < 256 ? (R + 3) / 4 : 256;
     hipLaunchKernelGGL(loss_reduce_kernel<false>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, depth, rgb, sdf, z_vals,
-                       gt_depth, gt_color, ray_mask, R, S, make_trunc(truncation), acc, (float*)nullptr, LossW{}, (float*)nullptr);
+                       gt_depth, gt_color, ray_mask, R, S, make_trunc(truncation), acc, (float*)nullptr, LossW{}, (float*)nullptr, 0);
     return eslam_check_launch("loss_reduce_kernel");
 }
 
@@ -125,7 +126,7 @@ extern "C" int eslam_loss_value(const float* depth, const float* rgb, const floa
     const int nwg = (R + 3) / 4 < 256 ? (R + 3) / 4 : 256;
     eslam_prof_begin(PROF_LOSS, (hipStream_t)stream);
     hipLaunchKernelGGL(loss_reduce_kernel<true>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, depth, rgb, sdf, z_vals,
-                       gt_depth, gt_color, ray_mask, R, S, make_trunc(truncation), acc, scratch, w, loss);
+                       gt_depth, gt_color, ray_mask, R, S, make_trunc(truncation), acc, scratch, w, loss, eslam_deterministic());
     eslam_prof_end(PROF_LOSS, (hipStream_t)stream);
     return eslam_check_launch("loss_reduce_kernel<final>");
 }

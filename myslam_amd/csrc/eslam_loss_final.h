@@ -77,6 +77,60 @@ __device__ __forceinline__ float loss_value_from_acc(const LossW w, const float*
            w.depth * (acc[A_S_DEPTH] / acc[A_N_DEPTH]);
 }
 
+// Deterministic variant (ESLAM_DETERMINISTIC=1): the float atomics above add the workgroups' sums in arrival order, so the
+// last bits of acc - and of everything scaled by it - change from run to run.  Here every workgroup stores its sums into a
+// slot of its own (write-through stores, drained before the ticket is drawn: MI355X_MICROARCH.md, "Valid forms"), and the
+// workgroup that draws the last ticket adds the slots in a fixed order.  scratch: [0] ticket, slots from float 32 on, 16
+// floats per workgroup (eslam_loss_scratch_floats).
+__device__ __forceinline__ void loss_finalize_det(float tot, float* __restrict__ scratch, float* __restrict__ acc,
+                                                  const LossW w, float* __restrict__ loss) {
+    __shared__ unsigned ticket_d;
+    __shared__ float part[4][16];
+    __shared__ float fin_d[16];
+    float* slots = scratch + 32;
+    if (threadIdx.x < 16)
+        __hip_atomic_store(slots + (size_t)blockIdx.x * 16 + threadIdx.x, threadIdx.x < A_COUNT ? tot : 0.0f, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) ticket_d = atomicAdd((unsigned*)scratch, 1u);
+    __syncthreads();
+    if (ticket_d != gridDim.x - 1) return;
+    // thread t adds slots t, t + 256, ... of every accumulator; then a fixed shuffle tree and the four waves in order
+    float p[A_COUNT];
+#pragma unroll
+    for (int k = 0; k < A_COUNT; ++k) p[k] = 0.0f;
+    for (unsigned s = threadIdx.x; s < gridDim.x; s += blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < A_COUNT; ++k)
+            p[k] += __hip_atomic_load(slots + (size_t)s * 16 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < A_COUNT; ++k) {
+        const float t = wave_sum(p[k]);
+        if (lane == 0 && wave < 4) part[wave][k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float v = 0.0f;
+        if (threadIdx.x < A_COUNT) {
+            const int nw = (blockDim.x + 63) >> 6;
+            for (int q = 0; q < nw && q < 4; ++q) v += part[q][threadIdx.x];
+        }
+        fin_d[threadIdx.x] = v;
+        acc[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (loss)
+            loss[0] = w.fs * (fin_d[A_S_FRONT] / fin_d[A_N_FRONT]) + w.center * (fin_d[A_S_CENTER] / fin_d[A_N_CENTER]) +
+                      w.tail * (fin_d[A_S_TAIL] / fin_d[A_N_TAIL]) + w.color * (fin_d[A_S_COLOR] / fin_d[A_N_COLOR]) +
+                      w.depth * (fin_d[A_S_DEPTH] / fin_d[A_N_DEPTH]);
+        atomicExch((unsigned*)scratch, 0u);
+    }
+}
+
 // Called by ALL threads of a workgroup (>= 64 threads); `tot` = this workgroup's sum of accumulator threadIdx.x (threads
 // 0 .. A_COUNT-1).  scratch: [0] ticket counter (unsigned); accumulator k at scratch[32 * (k + 1)] - one 128-B line each,
 // so the float atomics of different accumulators go to different memory channels.  Everything is exchanged through

@@ -106,7 +106,10 @@ struct RayBwdIn {                  // MODE >= 1: what the composite backward of 
 //         the global set sizes in li.acc: loss gradient, composite backward and decoder backward are ONE launch.
 // WGRAD = false: decoders are frozen (tracking, reference src/Tracker.py:111-112): only g_feat is produced, the
 // parameter-gradient contractions (28 of the 68 MFMAs per block), their LDS transposes and the slabs are skipped.
-template <int MODE, bool WGRAD>
+// LOWP: the mixed-precision tile (eslam_decode_tile.h): hidden layers recomputed and every product of the backward pass on
+// bf16 MFMA (16x16x32 / 16x16x16) with float32 accumulation - 15 MFMAs of 16 cycles per 16 points and decoder instead of
+// 68 of 32 cycles; features, activations' masks, biases and all accumulators stay float32.
+template <int MODE, bool WGRAD, bool LOWP>
 __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t dec, const float* __restrict__ feat,
                                                       const float* __restrict__ g_o, int64_t N,
                                                       float* __restrict__ g_feat, float* __restrict__ slabs,
@@ -114,7 +117,8 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
     __shared__ __attribute__((aligned(16))) float wlds[2 * DEC_LDS];
     __shared__ __attribute__((aligned(16))) float tiles[4][4][16 * TP];   // per wave: gz1, gz2, h1, h2 (as [pt][j])
     __shared__ __attribute__((aligned(16))) float gtile[4][64 * 4];       // per wave: g_o of the tile [pt][o]
-    stage_decoder_weights(wlds, dec, threadIdx.x, blockDim.x);
+    if (LOWP) stage_decoder_weights_lowp(wlds, dec, threadIdx.x, blockDim.x);
+    else stage_decoder_weights(wlds, dec, threadIdx.x, blockDim.x);
     __syncthreads();
 
     const int d = blockIdx.y;                         // 0 = sdf decoder, 1 = colour decoder
@@ -130,8 +134,21 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
     float* gt = gtile[wave];
 
     DecFrag f;
-    load_dec_frag(f, L, r, q);
     float w3col[4], w2t[4], w1t[4][4];
+    DecFragLP fl;
+    short4_t w3colp = {0, 0, 0, 0}, w2tp = {0, 0, 0, 0}, w1tp[4];
+    if (LOWP) {
+        const short* W = lp_weights(wlds, d);
+        load_dec_frag_lp(fl, W, lp_biases(wlds, d), r, q);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            if (q == 0) w3colp[jj] = W[LP_W3 + jj * 16 + r];                 // A[i = j = r][k = o = jj]: W3pad[o][j]
+            w2tp[jj] = W[LP_W2 + (4 * q + jj) * 16 + r];                     // A[i = k' = r][k = j = 4q+jj]: W2[j][k']
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) w1tp[mb][jj] = W[LP_W1 + (4 * q + jj) * 64 + 16 * mb + r];   // W1[j][f = 16 mb + r]
+        }
+    } else {
+    load_dec_frag(f, L, r, q);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         w3col[ks] = L[DEC_W3 + ks * 16 + r];                    // W3pad[o = ks][j = r]
@@ -139,6 +156,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)                          // row r of row block mb <-> feature (mb>>1)*32 + 16*(mb&1) + r:
             w1t[mb][ks] = L[DEC_W1 + (4 * q + ks) * 64 + (mb >> 1) * 32 + 16 * (mb & 1) + r];   // lane q then holds piece q
+    }
     }
 
     float4_t gW1[4], gW2, gW3, gb1, gb2;
@@ -160,11 +178,12 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
         // computed: at 2 waves per SIMD nothing else hides the ~2k-cycle load latency.
         auto load_block = [&](int b, float4_t v[4]) {
             const int64_t pt = min(p0 + 16 * b + gp, N - 1);
-            const float* fp = feat + pt * 128 + d * 64 + 4 * gq;
+            // float32 path: piece gq = channels 4gq.., 16+4gq.. of a level; mixed precision: channels 8gq..8gq+7
+            const float* fp = feat + pt * 128 + d * 64 + (LOWP ? 8 : 4) * gq;
             v[0] = *(const float4_t*)(fp);
-            v[1] = *(const float4_t*)(fp + 16);
+            v[1] = *(const float4_t*)(fp + (LOWP ? 4 : 16));
             v[2] = *(const float4_t*)(fp + 32);
-            v[3] = *(const float4_t*)(fp + 48);
+            v[3] = *(const float4_t*)(fp + (LOWP ? 36 : 48));
         };
         float4_t fnext[4];
         load_block(0, fnext);
@@ -187,7 +206,41 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
                 }
             }
             to_mfma_role<true, 16>(ft, lane);
-            float4_t h1, h2;
+            float4_t h1, h2, gz1, gz2;
+            const float4_t zero4 = (float4_t){0.f, 0.f, 0.f, 0.f};
+            float gf[16];
+            if (LOWP) {
+                float4_t a1, a2;
+                mlp_hidden_lp(fl, ft, a1, a2);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { h1[i] = fmaxf(a1[i], 0.f); h2[i] = fmaxf(a2[i], 0.f); }
+                // g_h2^T = W3^T . g_o^T: B[k = o][col = point] lives on the q == 0 lanes; go is in sample role (lane = point of the tile)
+                const float s0 = __shfl(go[0], 16 * b + r, WAVE), s1 = __shfl(go[1], 16 * b + r, WAVE), s2 = __shfl(go[2], 16 * b + r, WAVE);
+                const short4_t bgo = (q == 0) ? pack4(s0, s1, s2, 0.f) : (short4_t){0, 0, 0, 0};
+                const float4_t gh2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w3colp, bgo, zero4, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gz2[i] = a2[i] > 0.0f ? gh2[i] : 0.0f;
+                const float4_t gh1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w2tp, pack4(gz2[0], gz2[1], gz2[2], gz2[3]), zero4, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gz1[i] = a1[i] > 0.0f ? gh1[i] : 0.0f;
+                gb1 += gz1;
+                gb2 += gz2;
+                // g_feat^T = W1^T . g_z1^T: row block mb = features 16 mb .. 16 mb + 15, lane (r, q) receives 16 mb + 4q + reg
+                const short4_t bz1 = pack4(gz1[0], gz1[1], gz1[2], gz1[3]);
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    const float4_t acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w1tp[mb], bz1, zero4, 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gf[4 * mb + i] = acc[i];
+                }
+                to_gather_role<true, 16>(gf, lane);
+                if (p0 + 16 * b + gp < p0 + nvalid) {       // gather-role lane (point, g): features 16 mb + 4 g + i
+                    float* dst = g_feat + (p0 + 16 * b + gp) * 128 + d * 64 + 4 * gq;
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb)
+                        *(float4_t*)(dst + 16 * mb) = (float4_t){gf[4 * mb], gf[4 * mb + 1], gf[4 * mb + 2], gf[4 * mb + 3]};
+                }
+            } else {
             mlp_hidden(f, ft, h1, h2);
 
             // g_h2^T = W3^T . g_o^T   (K = (block', o); only block' == b contributes)
@@ -195,21 +248,18 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
             const bool mine = (q == b);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) gh2 = mfma16(mine ? w3col[ks] : 0.0f, go[ks], gh2);
-            float4_t gz2;
 #pragma unroll
             for (int i = 0; i < 4; ++i) gz2[i] = h2[i] > 0.0f ? gh2[i] : 0.0f;
             // g_h1^T = W2^T . g_z2^T
             float4_t gh1 = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) gh1 = mfma16(w2t[ks], gz2[ks], gh1);
-            float4_t gz1;
 #pragma unroll
             for (int i = 0; i < 4; ++i) gz1[i] = h1[i] > 0.0f ? gh1[i] : 0.0f;
             gb1 += gz1;
             gb2 += gz2;
 
             // g_feat^T = W1^T . g_z1^T, four row blocks ordered so that MFMA-role lane (r, q) receives piece q of point r
-            float gf[16];
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
                 float4_t acc = (float4_t){0.f, 0.f, 0.f, 0.f};
@@ -220,6 +270,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
             }
             to_gather_role<true, 16>(gf, lane);
             if (p0 + 16 * b + gp < p0 + nvalid) store_features(g_feat, p0 + 16 * b + gp, d, gq, gf);
+            }
             if (!WGRAD) continue;
 
             // transposes through LDS: D layout (rows 4q+reg, col = point r) -> [point][row]
@@ -240,6 +291,17 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
                 bh2[ks] = th2[prow * TP + r];
                 ago[ks] = (r < 4) ? gt[(16 * b + prow) * 4 + r] : 0.0f;
             }
+            if (LOWP) {      // the same contractions over the block's 16 points, K = 16 in one bf16 MFMA each
+                gW2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pack4(az2[0], az2[1], az2[2], az2[3]),
+                                                                pack4(bh1[0], bh1[1], bh1[2], bh1[3]), gW2, 0, 0, 0);
+                gW3 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pack4(ago[0], ago[1], ago[2], ago[3]),
+                                                                pack4(bh2[0], bh2[1], bh2[2], bh2[3]), gW3, 0, 0, 0);
+                const short4_t a1p = pack4(az1[0], az1[1], az1[2], az1[3]);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    gW1[nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1p, pack4(fbk[0][nb], fbk[1][nb], fbk[2][nb], fbk[3][nb]),
+                                                                        gW1[nb], 0, 0, 0);
+            } else {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 gW2 = mfma16(az2[ks], bh1[ks], gW2);              // g_W2[j][k'] : rows j = 4q+reg, col k' = r
@@ -250,6 +312,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
             for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb) gW1[nb] = mfma16(az1[ks], fbk[ks][nb], gW1[nb]);
+            }
             }
             WAVE_SYNC();
         }
@@ -581,6 +644,7 @@ __global__ __launch_bounds__(256, 2) void coord_bwd_kernel(const PlaneSet planes
 // ---------------------------------------------------------------------------------------------------------
 bool eslam_planes_channels_last(const eslam_plane_t* planes, int first, int count);
 int eslam_validate_planes(const eslam_plane_t* planes, int first, int count);
+int eslam_planes_lowp(const eslam_plane_t* planes);
 
 static Bound make_bound(const float* b6) {
     Bound b;
@@ -651,12 +715,22 @@ static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, 
     rb.beta_parts = render ? beta_parts : nullptr;
     const LossGradIn none = {};
     eslam_prof_begin(PROF_MLP_BWD, st);
-#define LAUNCH_MB(MD, WG) \
-    hipLaunchKernelGGL((mlp_bwd_kernel<MD, WG>), dim3(nwg, 2), dim3(256), 0, st, *dec, feat, g_o, N, g_feat, slabs, rb, \
+#define LAUNCH_MB(MD, WG, LP) \
+    hipLaunchKernelGGL((mlp_bwd_kernel<MD, WG, LP>), dim3(nwg, 2), dim3(256), 0, st, *dec, feat, g_o, N, g_feat, slabs, rb, \
                        li ? *li : none)
-    if (mode == 0) { if (g_dec) LAUNCH_MB(0, true); else LAUNCH_MB(0, false); }
-    else if (mode == 1) { if (g_dec) LAUNCH_MB(1, true); else LAUNCH_MB(1, false); }
-    else { if (g_dec) LAUNCH_MB(2, true); else LAUNCH_MB(2, false); }
+    const int lowp = eslam_planes_lowp(planes);
+    if (lowp < 0) return 1;
+    if (lowp) {
+        if (mode == 0 || g_out_a) {
+            eslam_set_error("mixed precision: only the ray backward to planes and decoders is built (no point / pose gradients)");
+            return 1;
+        }
+        if (mode == 1) { if (g_dec) LAUNCH_MB(1, true, true); else LAUNCH_MB(1, false, true); }
+        else { if (g_dec) LAUNCH_MB(2, true, true); else LAUNCH_MB(2, false, true); }
+    }
+    else if (mode == 0) { if (g_dec) LAUNCH_MB(0, true, false); else LAUNCH_MB(0, false, false); }
+    else if (mode == 1) { if (g_dec) LAUNCH_MB(1, true, false); else LAUNCH_MB(1, false, false); }
+    else { if (g_dec) LAUNCH_MB(2, true, false); else LAUNCH_MB(2, false, false); }
 #undef LAUNCH_MB
     eslam_prof_end(PROF_MLP_BWD, st);
     if (int rc = eslam_check_launch("mlp_bwd_kernel")) return rc;

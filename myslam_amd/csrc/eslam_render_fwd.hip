@@ -22,9 +22,11 @@ struct LossIn {
     float* loss;
     Trunc tr;
     LossW w;
+    int det;               // ESLAM_DETERMINISTIC: fixed-order reduction of the workgroups' sums
 };
 
-template <bool CL, bool SAVE, bool LOSS>
+// LOWP: the mixed-precision tile of eslam_decode_tile.h (fp16 plane copies, bf16 MFMA decoders); channels-last only.
+template <bool CL, bool SAVE, bool LOSS, bool LOWP>
 #ifndef FWD_WAVES
 #define FWD_WAVES 2            // waves per SIMD the gather kernels are compiled for: with one plane of loads in flight
                                // ahead of the FMAs the forward kernel needs 195 VGPRs; 2 waves/SIMD measured fastest
@@ -41,7 +43,9 @@ __global__ __launch_bounds__(256, FWD_WAVES) void render_fwd_kernel(const PlaneS
     // (eslam_sample_z_all_rng): advance the step for the next iteration (of a replayed graph)
     if (rng_bump && blockIdx.x == 0 && threadIdx.x == 0) rng_bump[0] += 1u;
     __shared__ __attribute__((aligned(16))) float wlds[2 * DEC_LDS];
-    stage_decoder_weights(wlds, dec, threadIdx.x, blockDim.x);
+    static_assert(LP_LDS_FLOATS <= 2 * DEC_LDS, "the bf16 weight image shares the float32 image's LDS");
+    if (LOWP) stage_decoder_weights_lowp(wlds, dec, threadIdx.x, blockDim.x);
+    else stage_decoder_weights(wlds, dec, threadIdx.x, blockDim.x);
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(256, FWD_WAVES) void render_fwd_kernel(const PlaneS
         float4_t out[2];
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
-            out[d] = *(const float4_t*)(wlds + d * DEC_LDS + DEC_B3);
+            out[d] = LOWP ? *(const float4_t*)(lp_biases(wlds, d) + 32) : *(const float4_t*)(wlds + d * DEC_LDS + DEC_B3);
 #pragma unroll 1
             for (int b = 0; b < nblk; ++b) {
                 const int oz0 = opaque_zero(b);
@@ -91,6 +95,19 @@ __global__ __launch_bounds__(256, FWD_WAVES) void render_fwd_kernel(const PlaneS
                 const float py = norm_coord(oy + dy * zb, bnd.lo[1], bnd.hi[1]);
                 const float pz = norm_coord(oz + dz * zb, bnd.lo[2], bnd.hi[2]);
                 float feat[16];
+                if (LOWP) {
+                    gather_features_half(planes, d, px, py, pz, gq, feat, oz0);
+                    if (SAVE) {
+                        if (sb < S) store_features_lp(feat_out, (int64_t)ray * S + sb, d, gq, feat);
+                    }
+                    to_mfma_role<true, 16>(feat, lane);
+                    DecFragLP fl;
+                    load_dec_frag_lp(fl, lp_weights(wlds, d) + oz0, lp_biases(wlds, d) + oz0, r, q);
+                    float4_t a1, a2;
+                    mlp_hidden_lp(fl, feat, a1, a2);
+                    mlp_out_accum_lp(fl, a2, b, r, out[d]);
+                    continue;
+                }
                 gather_features<CL>(planes, d, px, py, pz, gq, feat, oz0);
                 if (SAVE) {
                     if (sb < S) store_features(feat_out, (int64_t)ray * S + sb, d, gq, feat);
@@ -166,7 +183,8 @@ __global__ __launch_bounds__(256, FWD_WAVES) void render_fwd_kernel(const PlaneS
         float tot = 0.0f;
         if (threadIdx.x < A_COUNT)
             tot = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        loss_finalize(tot, li.scratch, li.acc, li.w, li.loss);
+        if (li.det) loss_finalize_det(tot, li.scratch, li.acc, li.w, li.loss);
+        else loss_finalize(tot, li.scratch, li.acc, li.w, li.loss);
     }
 }
 
@@ -244,6 +262,7 @@ __global__ __launch_bounds__(256, FWD_WAVES) void decode_fwd_kernel(const PlaneS
 // ---------------------------------------------------------------------------------------------------------
 bool eslam_planes_channels_last(const eslam_plane_t* planes, int first, int count);
 int eslam_validate_planes(const eslam_plane_t* planes, int first, int count);
+int eslam_planes_lowp(const eslam_plane_t* planes);
 static Bound make_bound(const float* b6) {
     Bound b;
     for (int k = 0; k < 3; ++k) {
@@ -281,10 +300,18 @@ static int render_fwd_common(const char* who, const eslam_plane_t* planes, const
     hipStream_t st = (hipStream_t)stream;
     const LossIn none = {};
 #define LAUNCH(CLv, SV, LS)                                                                                             \
-    hipLaunchKernelGGL((render_fwd_kernel<CLv, SV, LS>), grid, block, 0, st, ps, *dec, bnd, rays_o, rays_d, z_vals, R, \
+    hipLaunchKernelGGL((render_fwd_kernel<CLv, SV, LS, false>), grid, block, 0, st, ps, *dec, bnd, rays_o, rays_d, z_vals, R, \
+                       S, depth, rgb, sdf, raw_rgb, feat, (const int*)ray_order, LS ? *li : none, rng_bump)
+#define LAUNCH_LP(SV, LS)                                                                                               \
+    hipLaunchKernelGGL((render_fwd_kernel<true, SV, LS, true>), grid, block, 0, st, ps, *dec, bnd, rays_o, rays_d, z_vals, R, \
                        S, depth, rgb, sdf, raw_rgb, feat, (const int*)ray_order, LS ? *li : none, rng_bump)
     eslam_prof_begin(PROF_RENDER_FWD, st);
-    if (li) {
+    const int lowp = eslam_planes_lowp(planes);
+    if (lowp < 0) return 1;
+    if (lowp) {
+        if (li) { if (save) LAUNCH_LP(true, true); else LAUNCH_LP(false, true); }
+        else { if (save) LAUNCH_LP(true, false); else LAUNCH_LP(false, false); }
+    } else if (li) {
         if (cl && save) LAUNCH(true, true, true);
         else if (cl) LAUNCH(true, false, true);
         else if (save) LAUNCH(false, true, true);
@@ -296,6 +323,7 @@ static int render_fwd_common(const char* who, const eslam_plane_t* planes, const
         else LAUNCH(false, false, false);
     }
 #undef LAUNCH
+#undef LAUNCH_LP
     eslam_prof_end(PROF_RENDER_FWD, st);
     return eslam_check_launch("render_fwd_kernel");
 }
@@ -325,6 +353,7 @@ extern "C" int eslam_render_fwd_loss(const eslam_plane_t* planes, const eslam_de
     LossIn li;
     li.gt_depth = gt_depth; li.gt_color = gt_color; li.ray_mask = ray_mask;
     li.scratch = scratch; li.acc = acc; li.loss = loss;
+    li.det = eslam_deterministic();
     li.tr = make_trunc(truncation);
     li.w = LossW{weights5_host[0], weights5_host[1], weights5_host[2], weights5_host[3], weights5_host[4]};
     return render_fwd_common("eslam_render_fwd_loss", planes, dec, bound6_host, rays_o, rays_d, z_vals, R, S, depth, rgb,

@@ -20,6 +20,7 @@
 //                     lane = (x-corner, channel): consecutive entries of one cell are summed in two registers (rows
 //                     y0, y1) and each cell is written once with two 256-B-shaped float atomics.
 #include <stdlib.h>
+#include <type_traits>
 #include "eslam_decode_tile.h"
 
 #define SORT_MAX 8192
@@ -258,7 +259,13 @@ __global__ __launch_bounds__(1024) void ray_order_kernel(const float* __restrict
 //   LDS + one word of flags) to `records`; PHASE 2 (inside eslam_render_bwd) reads that image back - 48 KB of coalesced
 //   loads instead of 33 us of latency-bound cell arithmetic and sorting in front of the first atomic - and walks it.
 #define REC_META 4                                   // words behind the LDS image: [0] = swap | valid << 1
-template <bool RENDER, int DBG, int NT, int PHASE>
+//   DET (ESLAM_DETERMINISTIC=1): the sums of a cell are formed in 64-bit fixed point (2^-44 units: integer adds commute, so
+//   neither the arbitrary order of the counting sort's tickets inside a cell, nor the order in which workgroups' atomics
+//   reach a texel, nor the ray order itself can change a bit of the result) and added to an int64 shadow of the gradient
+//   planes; scatter_fixed_to_float_kernel then adds the shadow to the float gradients and clears it.
+#define FIX_SCALE 17592186044416.0f                  // 2^44: |contribution| < 5e5, resolution 5.7e-14
+struct ShadowOff { int64_t o[NPL]; };
+template <bool RENDER, int DBG, int NT, int PHASE, bool DET>
 __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes, const Bound bnd,
                                                           const float* __restrict__ rays_o,
                                                           const float* __restrict__ rays_d,
@@ -266,7 +273,8 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
                                                           const int* __restrict__ perm, int R, int S,
                                                           const float* __restrict__ g_feat, int bundle,
                                                           int allow_counting, int nbundles, int xcd_map,
-                                                          unsigned* __restrict__ records) {
+                                                          unsigned* __restrict__ records, long long* __restrict__ shadow,
+                                                          const ShadowOff shoff) {
     constexpr int dbg_mode = DBG;
     constexpr int BM = 4 * NT;
     constexpr int SLOT_BITS = (BM == 1024) ? 10 : 11;
@@ -561,7 +569,8 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
     const char* __restrict__ gcol = (const char*)(g_feat + d * 64 + lvl * 32);     // + row * 512 + c * 4 bytes
     unsigned cur_xy = PAD_XY;                  // cell being accumulated (PAD_XY: none / padding, never flushed)
     unsigned last_xy = PAD_XY;                 // xy of the last entry of the previous block
-    float acc0 = 0.f, acc1 = 0.f;
+    typedef typename std::conditional<DET, long long, float>::type acc_t;
+    acc_t acc0 = 0, acc1 = 0;
     const int e0 = wave * 256;
 
     // Flush of a finished cell: lane (hx, c) adds its two sums (major-axis corners 0 and 1) for its minor-axis corner.
@@ -570,17 +579,22 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
     // ONE scalar ALU the walk was SALU-bound (11 scalar instructions per entry).
     const unsigned lane_off = (unsigned)(c * psc) << 2;
     const unsigned dm_bytes = (unsigned)(swap ? psy : psx) << 2, dM_bytes = (unsigned)(swap ? psx : psy) << 2;
-    char* __restrict__ gbytes = (char*)grad;
+    char* __restrict__ gbytes = DET ? (char*)(shadow + shoff.o[pi]) : (char*)grad;
     auto flush = [&](bool lower_half_only) {
         if (cur_xy != PAD_XY) {
             const unsigned o0 = (cur_xy & ~3u) + lane_off + ((cur_xy & 1u) & (unsigned)hx) * dm_bytes;
             const unsigned o1 = o0 + ((cur_xy >> 1) & 1u) * dM_bytes;
-            if (dbg_mode != 1) {
-                if (!lower_half_only || hx == 0) {
-                    atomicAdd((float*)(gbytes + o0), acc0);
-                    atomicAdd((float*)(gbytes + o1), acc1);
+            if (DET) {
+                if (!lower_half_only || hx == 0) {           // the shadow mirrors the plane element for element: 8 bytes each
+                    atomicAdd((unsigned long long*)(gbytes + 2 * (size_t)o0), (unsigned long long)acc0);
+                    atomicAdd((unsigned long long*)(gbytes + 2 * (size_t)o1), (unsigned long long)acc1);
                 }
-            } else if (acc0 == 1.2345e30f) *(float*)(gbytes + o0) = acc1;      // profiling only: walk without atomics
+            } else if (dbg_mode != 1) {
+                if (!lower_half_only || hx == 0) {
+                    atomicAdd((float*)(gbytes + o0), (float)acc0);
+                    atomicAdd((float*)(gbytes + o1), (float)acc1);
+                }
+            } else if ((float)acc0 == 1.2345e30f) *(float*)(gbytes + o0) = (float)acc1;      // profiling only: walk without atomics
         }
     };
 
@@ -615,19 +629,24 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
             if (((rec).adjacent >> idx) & 1ull) {                                             \
                 /* next cell along the minor axis: its first texel column is our second one - keep those sums */ \
                 flush(true);                                                                  \
-                const float s0 = __shfl_xor(acc0, 32, WAVE), s1 = __shfl_xor(acc1, 32, WAVE); \
-                acc0 = hx ? 0.f : s0;                                                         \
-                acc1 = hx ? 0.f : s1;                                                         \
+                const acc_t s0 = __shfl_xor(acc0, 32, WAVE), s1 = __shfl_xor(acc1, 32, WAVE); \
+                acc0 = hx ? (acc_t)0 : s0;                                                    \
+                acc1 = hx ? (acc_t)0 : s1;                                                    \
             } else {                                                                          \
                 flush(false);                                                                 \
-                acc0 = 0.f;                                                                   \
-                acc1 = 0.f;                                                                   \
+                acc0 = 0;                                                                     \
+                acc1 = 0;                                                                     \
             }                                                                                 \
             cur_xy = (unsigned)__builtin_amdgcn_readlane((int)(rec).xy, idx);                 \
         }                                                                                     \
         const float g = buf[t];        /* padding entries have zero weights and belong to no cell */ \
-        acc0 += g * w2[0];                                                                    \
-        acc1 += g * w2[1];                                                                    \
+        if (DET) {                                                                            \
+            acc0 += (acc_t)__float2ll_rn((g * w2[0]) * FIX_SCALE);                            \
+            acc1 += (acc_t)__float2ll_rn((g * w2[1]) * FIX_SCALE);                            \
+        } else {                                                                              \
+            acc0 += (acc_t)(g * w2[0]);                                                       \
+            acc1 += (acc_t)(g * w2[1]);                                                       \
+        }                                                                                     \
     }
 
     const int nblk = 256 / WAVE;
@@ -658,6 +677,18 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
 #undef LOAD_HALF
 #undef WALK_HALF
     flush(false);
+}
+
+// deterministic mode: float gradient += shadow * 2^-44, shadow cleared (it is all zero again for the next call)
+__global__ __launch_bounds__(256) void scatter_fixed_to_float_kernel(float* __restrict__ grad, long long* __restrict__ shadow,
+                                                                     int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const long long v = shadow[i];
+        if (v != 0) {
+            grad[i] += (float)((double)v * (1.0 / 17592186044416.0));
+            shadow[i] = 0;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -829,11 +860,58 @@ int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float*
     dim3 grid(nbundles, NPL);
     if (xcd_map) grid = dim3(((nbundles * 4 + 7) / 8) * 8 * 3, 1);
 #define LAUNCH_SC(RD, DB, NTv, PH, PERM, SS)                                                                               \
-    hipLaunchKernelGGL((scatter_sort_kernel<RD, DB, NTv, PH>), grid, dim3(NTv), 0, st, ps, bnd, rays_o, rays_d, z_or_pts, \
-                       PERM, (int)R, SS, g_feat, bundle, counting, nbundles, xcd_map, records)
+    hipLaunchKernelGGL((scatter_sort_kernel<RD, DB, NTv, PH, false>), grid, dim3(NTv), 0, st, ps, bnd, rays_o, rays_d, z_or_pts, \
+                       PERM, (int)R, SS, g_feat, bundle, counting, nbundles, xcd_map, records, (long long*)nullptr, ShadowOff{})
     if (phase != 0 && (!render || !records)) {
         eslam_set_error("scatter: record phases need render mode and a record buffer");
         return 1;
+    }
+    if (eslam_deterministic() && phase == 0) {
+        // fixed-point scatter into the int64 shadow, then shadow -> float gradients (DET in the kernel's header comment)
+        ShadowOff so;
+        int64_t total = 0;
+        for (int i = 0; i < NPL; ++i) {
+            const int64_t numel = (int64_t)ESLAM_C_DIM * planes[i].h * planes[i].w;
+            const int64_t extent = (ESLAM_C_DIM - 1) * planes[i].stride_c + (int64_t)(planes[i].h - 1) * planes[i].stride_y +
+                                   (int64_t)(planes[i].w - 1) * planes[i].stride_x + 1;
+            if (extent != numel) {
+                eslam_set_error("scatter (deterministic mode): plane %d is not dense", i);
+                return 1;
+            }
+            so.o[i] = total;
+            total += numel;
+        }
+        static long long* shadow = nullptr;
+        static int64_t shadow_n = 0;
+        if (shadow_n < total) {       // first use (an eager warm-up call; hipMalloc cannot be captured into a graph)
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(st, &cs);
+            if (cs != hipStreamCaptureStatusNone) {
+                eslam_set_error("scatter (deterministic mode): run one eager iteration before capturing a graph");
+                return 1;
+            }
+            if (shadow) (void)hipFree(shadow);
+            if (hipMalloc(&shadow, (size_t)total * 8) != hipSuccess || hipMemset(shadow, 0, (size_t)total * 8) != hipSuccess) {
+                shadow = nullptr; shadow_n = 0;
+                eslam_set_error("scatter (deterministic mode): cannot allocate the %lld-element shadow", (long long)total);
+                return 2;
+            }
+            shadow_n = total;
+        }
+        if (render)
+            hipLaunchKernelGGL((scatter_sort_kernel<true, 0, 512, 0, true>), grid, dim3(512), 0, st, ps, bnd, rays_o, rays_d,
+                               z_or_pts, perm, (int)R, S, g_feat, bundle, counting, nbundles, xcd_map, (unsigned*)nullptr, shadow, so);
+        else
+            hipLaunchKernelGGL((scatter_sort_kernel<false, 0, 512, 0, true>), grid, dim3(512), 0, st, ps, bnd, rays_o, rays_d,
+                               z_or_pts, (const int*)nullptr, (int)R, 64, g_feat, bundle, counting, nbundles, xcd_map,
+                               (unsigned*)nullptr, shadow, so);
+        if (int rc = eslam_check_launch("scatter_sort_kernel<det>")) return rc;
+        for (int i = 0; i < NPL; ++i) {
+            const int64_t numel = (int64_t)ESLAM_C_DIM * planes[i].h * planes[i].w;
+            hipLaunchKernelGGL(scatter_fixed_to_float_kernel, dim3((unsigned)((numel + 255) / 256 < 2048 ? (numel + 255) / 256 : 2048)),
+                               dim3(256), 0, st, planes[i].grad, shadow + so.o[i], numel);
+        }
+        return eslam_check_launch("scatter_fixed_to_float_kernel");
     }
     if (render) {
         if (phase == 1) { if (bm == 1024) LAUNCH_SC(true, 0, 256, 1, perm, S); else LAUNCH_SC(true, 0, 512, 1, perm, S); }

@@ -211,6 +211,28 @@ def current_fused_loss():
     return _fused_loss
 
 
+_half_planes = None
+
+
+class mixed_precision:
+    """Context manager: Renderer.render_batch_ray calls issued inside run the mixed-precision kernels (BASELINE.json
+    configs[4]: texels gathered from float16 copies of the planes, decoders on bf16 MFMA forward and backward, float32
+    accumulation everywhere, plane gradients accumulated in float32 for the float32 masters).  half: a lowp.HalfPlanes (or any
+    object with `.flat`, the 12 float16 channels_last copies in all_planes order) - refresh it after every optimiser step."""
+
+    def __init__(self, half):
+        self.half = half
+
+    def __enter__(self):
+        global _half_planes
+        self._prev, _half_planes = _half_planes, self.half
+        return self.half
+
+    def __exit__(self, *a):
+        global _half_planes
+        _half_planes = self._prev
+
+
 def join_ray_order(device):
     """Make the current stream wait for the ray-ordering side stream.  RenderFn joins it in its backward; a caller that
     captures forward and backward into SEPARATE hipGraphs must join inside the forward's capture (parallel.py)."""
@@ -257,9 +279,13 @@ class RenderFn(torch.autograd.Function):
         R, S = z_vals.shape
         dev = rays_o.device
         lib = _hip.lib()
-        arr, _ = _hip.make_planes(_split_planes([p.detach() for p in planes]))
+        half = None if _half_planes is None else list(_half_planes.flat)
+        ctx.half = half
+        arr, _ = _hip.make_planes(_split_planes([p.detach() for p in planes]), half=half)
         dec, keep = _hip.make_decoders([p.detach() for p in params], beta.detach())
         needs = any(ctx.needs_input_grad)
+        if half is not None and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            raise RuntimeError("mixed precision: gradients with respect to the rays (pose) are not built; detach the rays")
         depth = torch.empty(R, device=dev)
         rgb = torch.empty(R, 3, device=dev)
         sdf = torch.empty(R, S, device=dev)
@@ -314,7 +340,7 @@ class RenderFn(torch.autograd.Function):
                                                      _hip.ptr(order) if _FWD_USES_ORDER else None,
                                                      _hip.ptr(st.gt_depth), _hip.ptr(st.gt_color),
                                                      st.truncation, w5, _hip.ptr(mask),
-                                                     _hip.ptr(_loss_scratch(dev)), _hip.ptr(fl.acc), _hip.ptr(fl.value),
+                                                     _hip.ptr(_loss_scratch(dev, R)), _hip.ptr(fl.acc), _hip.ptr(fl.value),
                                                      _take_rng_bump(dev), _hip.stream_handle(dev)), "eslam_render_fwd_loss")
                 ctx.lossctx = st
         if order_in is not None and side is not None:
@@ -353,7 +379,7 @@ class RenderFn(torch.autograd.Function):
             grads = sink.views[:12]
         elif need_planes:
             _, grads = _alloc_plane_grads(planes)
-        arr, _ = _hip.make_planes(_split_planes([p.detach() for p in planes]), grads)
+        arr, _ = _hip.make_planes(_split_planes([p.detach() for p in planes]), grads, half=ctx.half)
         dec, keep = _hip.make_decoders([p.detach() for p in params], beta.detach())
         if sink is not None:
             # the 12 decoder tensors follow the planes in the flat buffer in C-ABI order = the layout of g_dec
@@ -367,6 +393,10 @@ class RenderFn(torch.autograd.Function):
             g_beta = torch.empty(1, device=dev) if need[4] else None
         g_ro = torch.empty(R, 3, device=dev) if need_rays else None
         g_rd = torch.empty(R, 3, device=dev) if need_rays else None
+        if R == 0:        # the C entry returns at once for an empty batch: the gradient of nothing is zero, not uninitialised
+            for t in (g_dec, g_beta):
+                if t is not None:
+                    t.zero_()
         ws = torch.empty(lib.eslam_bwd_workspace_bytes(R * S), dtype=torch.uint8, device=dev)
         g_depth, g_rgb, g_sdf = _c(g_depth), _c(g_rgb), _c(g_sdf)
         fl = ctx.lossctx                 # a _LossState
@@ -694,12 +724,64 @@ def loss_reduce(depth, rgb, sdf, z_vals, gt_depth, gt_color, truncation, ray_mas
     return acc
 
 
-def _loss_scratch(dev):
-    """ESLAM_LOSS_SCRATCH floats per device: zeroed once here, then owned by eslam_loss_value's ticket scheme.  One per
-    device, not per stream: a graph capture runs on a stream of its own and must find the buffer of the warm-up (a
-    buffer created inside the capture would be re-zeroed by a captured fill on every replay).  Loss evaluations of one
-    process are therefore expected on one stream at a time - the reference's loops are single-stream."""
-    return _cached(("loss_scratch", dev.index), lambda: torch.zeros(32 * 17, device=dev))
+_scratch_slots = {}           # (device index, stream handle) -> scratch tensor
+_scratch_pool = {}            # device index -> [pre-zeroed pool tensor, floats handed out]
+_DEBUG_SCRATCH = os.environ.get("ESLAM_DEBUG_SCRATCH", "0") == "1"
+_SCRATCH_POOL_FLOATS = 1 << 20        # 4 MB per device: 8 streams of 32 768-ray deterministic scratch, or ~1900 plain ones
+
+
+def _loss_scratch(dev, n_rays=0):
+    """The scratch of the fused loss's ticket scheme (eslam_loss_value / eslam_render_fwd_loss): zeroed once, then owned by
+    the kernels, which leave it zeroed again.  ONE PER (device, stream): two streams of a process evaluating losses at the
+    same time must not share the running sums.  Slots come out of a pool that is zeroed when it is created - outside any
+    graph capture, by the warm-up iterations - because a buffer created inside a capture would be re-zeroed by a captured
+    fill on every replay.  (torch captures every graph on one shared capture stream: graphs that are to REPLAY concurrently
+    on different streams need their own slot - capture them under ops.fresh_loss_scratch().)
+    ESLAM_DEBUG_SCRATCH=1 checks on the host that the ticket counter is 0 before every use (a graph aborted between the
+    adds and the last ticket leaves it non-zero): one sync per loss, for debugging only."""
+    need = int(_hip.lib().eslam_loss_scratch_floats(int(n_rays)))
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, _scratch_epoch)
+    t = _scratch_slots.get(key)
+    if t is None or t.numel() < need:
+        pool = _scratch_pool.get(dev.index)
+        if pool is None or pool[1] + need > pool[0].numel():
+            pool = _scratch_pool[dev.index] = [torch.zeros(max(_SCRATCH_POOL_FLOATS, need), device=dev), 0]
+        t = pool[0][pool[1]:pool[1] + need]
+        pool[1] += (need + 31) // 32 * 32
+        _scratch_slots[key] = t
+    if _DEBUG_SCRATCH and not torch.cuda.is_current_stream_capturing():
+        if int(t[:1].view(torch.int32).item()) != 0:
+            reset_loss_scratch(dev)
+            raise RuntimeError("loss scratch: the ticket counter was not 0 on entry - a previous loss evaluation on this stream "
+                               "did not finish (aborted graph?) or two streams shared a scratch; it has been reset")
+    return t
+
+
+_scratch_epoch = 0
+
+
+class fresh_loss_scratch:
+    """Context manager: loss evaluations issued inside get scratch slots of their own (for a graph that will replay
+    concurrently with other graphs captured on torch's shared capture stream)."""
+
+    def __enter__(self):
+        global _scratch_epoch
+        self._prev = _scratch_epoch
+        _scratch_epoch = fresh_loss_scratch._next = getattr(fresh_loss_scratch, "_next", 0) + 1
+        return self
+
+    def __exit__(self, *a):
+        global _scratch_epoch
+        _scratch_epoch = self._prev
+
+
+def reset_loss_scratch(device=None):
+    """eslam_loss_scratch_reset on every scratch slot (of one device): back to the freshly zeroed state."""
+    for (di, _, _), t in _scratch_slots.items():
+        if device is None or torch.device(device).index == di:
+            with _hip.on_device(t.device):
+                _hip.check(_hip.lib().eslam_loss_scratch_reset(_hip.ptr(t), t.numel(), _hip.stream_handle(t.device)),
+                           "eslam_loss_scratch_reset")
 
 
 class MappingLossFn(torch.autograd.Function):
@@ -731,7 +813,7 @@ class MappingLossFn(torch.autograd.Function):
             acc = torch.empty(16, device=dev)
             with _hip.on_device(dev):
                 _hip.check(_hip.lib().eslam_loss_value(*[_hip.ptr(t) for t in args], R, S, float(truncation), w,
-                                                       _hip.ptr(ray_mask), _hip.ptr(_loss_scratch(dev)), _hip.ptr(acc),
+                                                       _hip.ptr(ray_mask), _hip.ptr(_loss_scratch(dev, R)), _hip.ptr(acc),
                                                        _hip.ptr(loss), _hip.stream_handle(dev)), "eslam_loss_value")
         else:
             if acc is None:

@@ -44,7 +44,11 @@ class Decoders(nn.Module):
         """decoders.py:87-105.  p_nor are already-normalised coordinates, so the kernel's normalisation is made the
         identity by passing the unit cube as bound."""
         p = p_nor.reshape(-1, 3)
-        if not (torch.is_grad_enabled() and (p.requires_grad or any(t.requires_grad for t in self.parameters()))):
+        # the no-autograd kernel only when NOTHING that feeds the sdf wants a gradient: points, decoders or the geometry planes
+        # (frozen decoders with trainable planes still back-propagate through grid_sample in the reference)
+        wants = p.requires_grad or any(t.requires_grad for t in self.parameters()) or \
+            any(t.requires_grad for grp in all_planes[:3] for t in grp)
+        if not (torch.is_grad_enabled() and wants):
             return ops.decode_sdf_only(p, _UNIT_BOUND, all_planes, self)
         return self._decode(p, _UNIT_BOUND, all_planes)[:, 3]
 

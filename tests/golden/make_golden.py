@@ -320,6 +320,79 @@ def render_img_case(ref, name="render_img_room0_30x44"):
     print(name, "ok: zero-depth pixels", int((gt_depth == 0).sum()), "rand calls", len(rng.calls))
 
 
+def tum_lists(n_rgb=60, stream=900):
+    """Synthetic TUM-format lists shared by the fixture and the tests: colour frames at ~30 Hz with jittered timestamps and a
+    gap, depth frames at a slightly different phase (some further than max_dt from any colour frame), poses at ~100 Hz."""
+    u = synth.hash_uniform((n_rgb,), stream).astype(np.float64)
+    t_rgb = 1305031000.0 + np.arange(n_rgb) / 30.0 + 0.004 * (u - 0.5)
+    t_rgb[40:] += 0.5                                      # a pause in the recording
+    v = synth.hash_uniform((n_rgb,), stream + 1).astype(np.float64)
+    t_dep = t_rgb + 0.02 + 0.13 * (v > 0.85)               # 15 % of the depth frames are 0.15 s late: no partner within 0.08 s
+    t_dep = np.delete(t_dep, [7, 8])                       # and two are missing
+    n_pose = 400
+    t_pose = t_rgb[0] - 0.05 + np.arange(n_pose) / 100.0   # ends before the last colour frames: those lose their pose
+    q = synth.hash_uniform((n_pose, 4), stream + 2).astype(np.float64) - 0.5
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    tr = synth.hash_uniform((n_pose, 3), stream + 3).astype(np.float64) * 2 - 1
+    return t_rgb, t_dep, t_pose, np.concatenate([tr, q], 1)
+
+
+def write_tum_lists(folder, t_rgb, t_dep, t_pose, vecs):
+    with open(os.path.join(folder, "rgb.txt"), "w") as f:
+        f.write("".join(f"{t:.6f} rgb/{t:.6f}.png\n" for t in t_rgb))
+    with open(os.path.join(folder, "depth.txt"), "w") as f:
+        f.write("".join(f"{t:.6f} depth/{t:.6f}.png\n" for t in t_dep))
+    with open(os.path.join(folder, "groundtruth.txt"), "w") as f:
+        f.write("# timestamp tx ty tz qx qy qz qw\n")
+        f.write("".join(f"{t:.4f} " + " ".join(f"{x:.6f}" for x in v) + "\n" for t, v in zip(t_pose, vecs)))
+
+
+def datasets_case(ref, name="datasets_lists"):
+    """The parts of the reference's dataset readers that do not need OpenCV (src/utils/datasets.py): TUM_RGBD.loadtum
+    (timestamp association, frame-rate thinning, re-basing, flip) on synthetic lists, Replica.load_poses and
+    ScanNet.load_poses on synthetic trajectories.  numpy 2 removed the np.unicode_ alias the reference's parse_list names:
+    it is restored for the duration of the call."""
+    import tempfile
+    from src.utils import datasets as rds
+    t_rgb, t_dep, t_pose, vecs = tum_lists()
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        write_tum_lists(d, t_rgb, t_dep, t_pose, vecs)
+        ns = SimpleNamespace()
+        ns.parse_list = lambda path, skiprows=0: rds.TUM_RGBD.parse_list(ns, path, skiprows)
+        ns.associate_frames = lambda a, b, c, max_dt=0.08: rds.TUM_RGBD.associate_frames(ns, a, b, c, max_dt)
+        ns.pose_matrix_from_quaternion = lambda v: rds.TUM_RGBD.pose_matrix_from_quaternion(ns, v)
+        had = hasattr(np, "unicode_")
+        if not had:
+            np.unicode_ = np.str_
+        try:
+            images, depths, poses = rds.TUM_RGBD.loadtum(ns, d, frame_rate=32)
+        finally:
+            if not had:
+                del np.unicode_
+        out["tum_images"] = np.array([os.path.relpath(p, d) for p in images])
+        out["tum_depths"] = np.array([os.path.relpath(p, d) for p in depths])
+        out["tum_poses"] = torch.stack(poses).numpy()
+        # Replica traj.txt (16 numbers per line) and ScanNet pose/<n>.txt (4 lines of 4)
+        K = 12
+        mats = keyframe_poses(K, scn.make_scene("room0"), stream=950).double().numpy()
+        with open(os.path.join(d, "traj.txt"), "w") as f:
+            f.write("".join(" ".join(f"{x:.9e}" for x in m.reshape(-1)) + "\n" for m in mats))
+        rns = SimpleNamespace(n_img=K)
+        rds.Replica.load_poses(rns, os.path.join(d, "traj.txt"))
+        out["replica_poses"] = torch.stack(rns.poses).numpy()
+        os.makedirs(os.path.join(d, "pose"))
+        for k, m in enumerate(mats):
+            with open(os.path.join(d, "pose", f"{k}.txt"), "w") as f:
+                f.write("".join(" ".join(f"{x:.6f}" for x in row) + "\n" for row in m))
+        sns = SimpleNamespace()
+        rds.ScanNet.load_poses(sns, os.path.join(d, "pose"))
+        out["scannet_poses"] = torch.stack(sns.poses).numpy()
+        out["mats"] = mats
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "ok:", len(out["tum_images"]), "TUM frames kept of", len(t_rgb))
+
+
 def keyframe_poses(K, sc, stream=700):
     """K camera poses inside the scene: yaw angles all round the compass (so some views overlap the current frame and
     some look away), small pitch, translation within 1 m of the AABB centre.  Shared by the fixture and the tests."""
@@ -379,6 +452,8 @@ def main():
         keyframe_overlap_case(ref)
     if want("render_img"):
         render_img_case(ref)
+    if want("datasets"):
+        datasets_case(ref)
     # BASELINE.json configs[0]: 200 rays x 32 samples (24+8), CPU plumbing case - stored in full
     if want("room0_200x32"):
         render_case(ref, "room0_200x32", "room0", 200, 24, 8, 0.0)

@@ -31,14 +31,14 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/eslam_hip.h but not exported"
         assert n in _hip.SIGNATURES, f"{n} has no ctypes prototype in myslam_amd/_hip.py"
-    assert lib.eslam_abi_version() == _hip.ABI_VERSION == 2
+    assert lib.eslam_abi_version() == _hip.ABI_VERSION == 3
     assert lib.eslam_bwd_workspace_bytes(262144) > 262144 * 128 * 4
     assert lib.eslam_bwd_workspace_bytes(-1) == -1
 
 
 def test_struct_layout_matches_header():
     from myslam_amd import _hip
-    assert ctypes.sizeof(_hip.PlaneDesc) == 8 + 8 + 4 + 4 + 3 * 8
+    assert ctypes.sizeof(_hip.PlaneDesc) == 8 + 8 + 4 + 4 + 3 * 8 + 8
     assert ctypes.sizeof(_hip.DecodersDesc) == 13 * 8
     assert ctypes.sizeof(_hip.AdamTensor) == 4 * 8 + 8 + 8
     assert _hip.N_DEC_PARAMS == 2 * (16 * 64 + 16 + 16 * 16 + 16) + 17 + 51

@@ -88,3 +88,51 @@ def test_graph_captured_loop_matches_eager_loop():
     print(f"sync-free eager: ATE rmse {ate_s['rmse']*100:.2f} cm, PSNR {q_s['psnr']:.2f} dB, depth L1 {q_s['depth_l1']*100:.2f} cm, {st_s}")
     assert st_s["tracking_iters"] == st_e["tracking_iters"] and "graphs" not in st_s
     assert ate_s["rmse"] < 0.02 and abs(q_s["psnr"] - q_e["psnr"]) < 1.5
+
+
+def test_room0_sized_loop_from_a_replica_format_sequence(tmp_path):
+    """BASELINE.json configs[2] at its stated shapes: the tracking + mapping loop with the reference's Replica settings
+    (680 x 1200 frames, room0 bound and planes, 2000 tracking pixels x 8 iterations per frame, 4000 mapping pixels x 15
+    iterations every 4th frame; configs/Replica/replica.yaml:10-14,25-26) over a sequence READ FROM DISK in the Replica
+    layout (results/frame*.jpg, results/depth*.png at png_depth_scale 6553.5, traj.txt) through the dataset reader.
+    No Replica data ships with the reference, so the frames are the analytic room's ('rich' variant: every view has relief),
+    written with PIL; 9 frames and 300 first-frame iterations keep the test short."""
+    import numpy as np
+    from types import SimpleNamespace
+    from PIL import Image
+    from myslam_amd import eval_ate, scene as scn, slam, synthscene
+    from myslam_amd.src.utils import datasets as ds
+    dev = torch.device("cuda:0")
+    sc = scn.make_scene("room0")
+    n_frames = 9
+    frames = synthscene.make_sequence(sc, n_frames, device=dev, variant="rich")
+    os.makedirs(tmp_path / "results")
+    with open(tmp_path / "traj.txt", "w") as f:
+        for k, color, depth, c2w in frames:
+            Image.fromarray((color.cpu().numpy() * 255).round().astype(np.uint8)).save(tmp_path / "results" / f"frame{k:06d}.jpg", quality=95)
+            Image.fromarray((depth.cpu().numpy() * 6553.5).round().astype(np.uint16)).save(tmp_path / "results" / f"depth{k:06d}.png")
+            m = c2w.cpu().double().numpy().copy()
+            m[:3, 1:3] *= -1                       # the file holds the dataset's camera convention; the reader flips it back
+            f.write(" ".join(f"{x:.9e}" for x in m.reshape(-1)) + "\n")
+    cfg = dict(dataset="replica", data=dict(input_folder=str(tmp_path)),
+               cam=dict(H=sc.H, W=sc.W, fx=sc.fx, fy=sc.fy, cx=sc.cx, cy=sc.cy, png_depth_scale=6553.5, crop_edge=0))
+    reader = ds.get_dataset(cfg, SimpleNamespace(input_folder=None), scale=1.0, device=dev)
+    assert len(reader) == n_frames
+    seq = []
+    for k in range(n_frames):
+        idx, color, depth, pose = reader[k]
+        assert tuple(depth.shape) == (680, 1200) and tuple(color.shape) == (680, 1200, 3)
+        assert float((depth.to(dev) - frames[k][2]).abs().max()) < 1.0 / 6553.5          # 16-bit quantisation only
+        assert float((color.to(dev).float() - frames[k][1]).abs().mean()) < 0.02          # JPEG
+        assert torch.allclose(pose, frames[k][3].cpu(), atol=1e-6)
+        seq.append((idx, color.float().to(dev), depth.to(dev), pose.to(dev)))
+    torch.manual_seed(0)
+    s = slam.Slam(sc, slam.SlamConfig(iters_first=300), device=dev, seed=0)        # every other setting: the reference's
+    est = s.run(seq)
+    assert s.stats["tracking_iters"] == 8 * (n_frames - 1) and s.stats["mapping_iters"] == 300 + 15 * 2
+    assert 1900 < s.stats["tracking_rays"] / s.stats["tracking_iters"] <= 2000      # 2000 pixels, a few fall on sensor holes
+    assert 3900 < s.stats["mapping_rays"] / s.stats["mapping_iters"] <= 4000
+    ate = eval_ate.evaluate([e.cpu().numpy() for e in est], [f[3].cpu().numpy() for f in frames])
+    q = s.render_quality(frames[4][1], frames[4][2], frames[4][3])
+    print(f"\nroom0-sized loop from disk: ATE rmse {ate['rmse']*100:.2f} cm, PSNR {q['psnr']:.2f} dB, depth L1 {q['depth_l1']*100:.2f} cm, {s.stats}")
+    assert ate["rmse"] < 0.03 and q["depth_l1"] < 0.08 and q["psnr"] > 17.0
