@@ -48,7 +48,8 @@ typedef struct {
                                (stride_c = 1, stride_x = 32: 64-byte texels).  When all 12 planes carry one, eslam_render_fwd*,
                                eslam_render_bwd* run the mixed-precision path of BASELINE.json configs[4]: texels gathered from
                                the half copies (float32 accumulation), decoders on bf16 MFMA forward AND backward, plane
-                               gradients accumulated in float32 into `grad` (the float32 master's gradient).        */
+                               gradients accumulated in float32 into `grad` (the float32 master's gradient).  The saved
+                               features `feat` then hold R*S*128 bf16 values (half the bytes of the float32 path's buffer). */
 } eslam_plane_t;
 
 typedef struct {            /* src/networks/decoders.py:47-60                                      */

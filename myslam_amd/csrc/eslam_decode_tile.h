@@ -368,12 +368,25 @@ __device__ __forceinline__ void gather_features_half(const PlaneSet& planes, int
     }
 }
 
-// features of the mixed-precision path in feat_out [N,128]: natural channel order, lane (point, piece g) owns channels 8g..8g+7
+// Features of the mixed-precision path are SAVED AS bf16 - the very values the decoders' first layer consumed - in
+// feat_out viewed as [N,128] shorts (half the bytes of the float32 path's buffer): natural channel order, gather-role lane
+// (point, piece g) owns channels 8g..8g+7 of each level (16 bytes; a quad of lanes 64 contiguous bytes).  The backward
+// pass's recompute is then bit-identical to the forward pass, and both of its reads of the features move half the bytes.
 __device__ __forceinline__ void store_features_lp(float* feat_out, int64_t pt, int d, int g, const float feat[16]) {
-    float* dst = feat_out + pt * 128 + d * 64 + 8 * g;
+    short* dst = (short*)feat_out + pt * 128 + d * 64 + 8 * g;
 #pragma unroll
     for (int lvl = 0; lvl < 2; ++lvl) {
-        *(float4_t*)(dst + lvl * 32) = (float4_t){feat[lvl * 8 + 0], feat[lvl * 8 + 1], feat[lvl * 8 + 2], feat[lvl * 8 + 3]};
-        *(float4_t*)(dst + lvl * 32 + 4) = (float4_t){feat[lvl * 8 + 4], feat[lvl * 8 + 5], feat[lvl * 8 + 6], feat[lvl * 8 + 7]};
+        short8_t v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = f2bf(feat[lvl * 8 + i]);
+        *(short8_t*)(dst + lvl * 32) = v;
     }
+}
+
+// hidden layers from B fragments that are already bf16 (the saved features of the backward pass)
+__device__ __forceinline__ void mlp_hidden_lp_bf(const DecFragLP& f, const short8_t bf[2], float4_t& a1, float4_t& a2) {
+    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w1[0], bf[0], f.b1, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w1[1], bf[1], a1, 0, 0, 0);
+    const short4_t h1b = pack4(fmaxf(a1[0], 0.f), fmaxf(a1[1], 0.f), fmaxf(a1[2], 0.f), fmaxf(a1[3], 0.f));
+    a2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(f.w2, h1b, f.b2, 0, 0, 0);
 }

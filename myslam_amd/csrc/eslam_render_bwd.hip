@@ -178,12 +178,18 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
         // computed: at 2 waves per SIMD nothing else hides the ~2k-cycle load latency.
         auto load_block = [&](int b, float4_t v[4]) {
             const int64_t pt = min(p0 + 16 * b + gp, N - 1);
-            // float32 path: piece gq = channels 4gq.., 16+4gq.. of a level; mixed precision: channels 8gq..8gq+7
-            const float* fp = feat + pt * 128 + d * 64 + (LOWP ? 8 : 4) * gq;
+            if (LOWP) {      // bf16 features (store_features_lp): channels 8gq..8gq+7 of each level, 16 bytes per level
+                const short* fp = (const short*)feat + pt * 128 + d * 64 + 8 * gq;
+                v[0] = *(const float4_t*)(fp);
+                v[1] = *(const float4_t*)(fp + 32);
+                v[2] = v[3] = (float4_t){0.f, 0.f, 0.f, 0.f};
+                return;
+            }
+            const float* fp = feat + pt * 128 + d * 64 + 4 * gq;     // piece gq = channels 4gq.., 16+4gq.. of a level
             v[0] = *(const float4_t*)(fp);
-            v[1] = *(const float4_t*)(fp + (LOWP ? 4 : 16));
+            v[1] = *(const float4_t*)(fp + 16);
             v[2] = *(const float4_t*)(fp + 32);
-            v[3] = *(const float4_t*)(fp + (LOWP ? 36 : 48));
+            v[3] = *(const float4_t*)(fp + 48);
         };
         float4_t fnext[4];
         load_block(0, fnext);
@@ -198,20 +204,32 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
             // the same rows again in the "feature on the lane" layout of the g_W1 contraction (B operand): requested
             // here so that the L1/L2 latency is covered by the 28 MFMAs of the recompute instead of stalling them later
             float4_t fbk[4];
+            short4_t fbkp[4];
             if (WGRAD) {
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const int64_t pk = min(p0 + 16 * b + 4 * q + ks, N - 1);
-                    fbk[ks] = *(const float4_t*)(feat + pk * 128 + d * 64 + 4 * r);
+                    if (LOWP) fbkp[ks] = *(const short4_t*)((const short*)feat + pk * 128 + d * 64 + 4 * r);
+                    else fbk[ks] = *(const float4_t*)(feat + pk * 128 + d * 64 + 4 * r);
                 }
             }
-            to_mfma_role<true, 16>(ft, lane);
+            if (LOWP) to_mfma_role<true, 8>(ft, lane);       // 8 registers of packed bf16 pairs
+            else to_mfma_role<true, 16>(ft, lane);
             float4_t h1, h2, gz1, gz2;
             const float4_t zero4 = (float4_t){0.f, 0.f, 0.f, 0.f};
             float gf[16];
             if (LOWP) {
                 float4_t a1, a2;
-                mlp_hidden_lp(fl, ft, a1, a2);
+                short8_t bfeat[2];
+#pragma unroll
+                for (int lvl = 0; lvl < 2; ++lvl)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const unsigned u = __builtin_bit_cast(unsigned, ft[lvl * 4 + i]);
+                        bfeat[lvl][2 * i] = (short)(u & 0xFFFFu);
+                        bfeat[lvl][2 * i + 1] = (short)(u >> 16);
+                    }
+                mlp_hidden_lp_bf(fl, bfeat, a1, a2);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { h1[i] = fmaxf(a1[i], 0.f); h2[i] = fmaxf(a2[i], 0.f); }
                 // g_h2^T = W3^T . g_o^T: B[k = o][col = point] lives on the q == 0 lanes; go is in sample role (lane = point of the tile)
@@ -299,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
                 const short4_t a1p = pack4(az1[0], az1[1], az1[2], az1[3]);
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb)
-                    gW1[nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1p, pack4(fbk[0][nb], fbk[1][nb], fbk[2][nb], fbk[3][nb]),
+                    gW1[nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1p, (short4_t){fbkp[0][nb], fbkp[1][nb], fbkp[2][nb], fbkp[3][nb]},
                                                                         gW1[nb], 0, 0, 0);
             } else {
 #pragma unroll

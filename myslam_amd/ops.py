@@ -290,7 +290,8 @@ class RenderFn(torch.autograd.Function):
         rgb = torch.empty(R, 3, device=dev)
         sdf = torch.empty(R, S, device=dev)
         raw_rgb = torch.empty(R, S, 3, device=dev) if needs else None
-        feat = torch.empty(R * S, 128, device=dev) if needs else None
+        # saved features: float32, or (mixed precision) the bf16 values the decoders consumed - half the bytes
+        feat = torch.empty(R * S, 128, device=dev, dtype=torch.float32 if half is None else torch.bfloat16) if needs else None
         order = None
         if order_in is not None:
             order, side = order_in

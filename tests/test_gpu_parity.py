@@ -410,8 +410,10 @@ def test_sharded_mapper_one_rank_rccl():
         for _ in range(6):
             lb = wb.step()
             ob.step()
-        # (run-to-run differences in the last bits of the gradients - float atomics - are amplified by Adam for
-        # near-zero gradients: lr * dg / eps per step; hence 3e-4, not the 1e-5 of a single backward)
+        # 1e-4 / 3e-4 (commit a6bd2ae widened them from 1e-5): the run-to-run noise of the float atomics' last bits, amplified by
+        # Adam for near-zero gradients (lr * dg / eps per step), is heavy-tailed - 1.6e-6 in one run of these 6 steps, 1.0e-5
+        # in the next.  tests/test_gpu_determinism.py shows that it IS noise: with ESLAM_DETERMINISTIC=1 the two loops agree
+        # bit for bit (0.0 <= 1e-5).
         assert abs(float(la) - float(lb)) <= 1e-4 * abs(float(lb))
         for a, b in zip(wa.params(), wb.params()):
             assert hp.rel_err(a.detach().cpu().numpy(), b.detach().cpu().numpy()) <= 3e-4
@@ -741,6 +743,62 @@ def test_mixed_precision_tolerance_study():
                    np.maximum(np.abs(o["depth"].detach().numpy()[hd]), 1e-3)).max())
     print(f"mixed precision vs the float64 oracle ({int(hd.sum())} rays): max|sdf| {e_sdf:.2e}  max|rgb| {e_rgb:.2e}  max rel depth {e_dep:.2e}")
     assert e_sdf < 5e-3 and e_rgb < 5e-3 and e_dep < 2e-2
+
+
+def test_mixed_precision_training_step_gradient_study():
+    """BASELINE.json configs[4] as a TRAINING configuration: forward and backward of a mapping iteration on the mixed-precision
+    kernels (fp16 plane copies, bf16-MFMA decoders both ways, float32 accumulation and float32 plane gradients) against
+    autograd over the float64 oracle on the freiburg1_desk fixture (5000 rays x 56 samples, 10 % depth-less).  A tolerance
+    STUDY: the gradients of a bf16 network are not the float32 network's to 1e-4; the bounds are what was measured, with
+    margin, and are recorded in DESIGN.md."""
+    from myslam_amd import lowp, losses, ops
+    from tests.test_oracle_golden import run_oracle
+    fx = hp.load("freiburg1_desk_5000x56_zero10")
+    dev = _dev()
+    sc, planes, dec, renderer = build(fx)
+    t_rand, t_uni, u = hp.rand_inputs(fx)
+    rand = tuple(None if t is None else t.to(dev) for t in (t_rand, t_uni, u))
+    ro = torch.from_numpy(fx["rays_o"]).to(dev)
+    rd = torch.from_numpy(fx["rays_d"]).to(dev)
+    gd = torch.from_numpy(fx["gt_depth"]).to(dev)
+    gc = torch.from_numpy(fx["gt_color"]).to(dev)
+    tr = float(fx["truncation"])
+    half = lowp.HalfPlanes(planes)
+    res = {}
+    for label in ("separate", "fused"):
+        for p in hp.flat_planes(planes) + list(dec.parameters()):
+            p.grad = None
+        with ops.mixed_precision(half):
+            if label == "fused":      # loss sums in the forward's epilogue, loss gradients inside the backward kernel
+                depth, color, sdf, z, pre = renderer.render_batch_ray_with_loss(planes, dec, rd, ro, dev, tr, gd, gc,
+                                                                                losses.MAPPING_W, _rand=rand)
+                loss = pre.loss
+            else:
+                depth, color, sdf, z = renderer.render_batch_ray(planes, dec, rd, ro, dev, tr, gt_depth=gd, _rand=rand)
+                loss = losses.mapping_loss(depth, color, sdf, z, gd, gc, tr)
+            loss.backward()
+        torch.cuda.synchronize()
+        res[label] = (float(loss), [p.grad.detach().clone() for p in hp.flat_planes(planes)],
+                      {k: p.grad.detach().clone() for k, p in dec.named_parameters()})
+    # the two formulations of the same mixed-precision step agree like the float32 ones do
+    assert abs(res["fused"][0] - res["separate"][0]) <= 1e-5 * abs(res["separate"][0])
+    for a, b in zip(res["fused"][1], res["separate"][1]):
+        assert hp.rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 1e-4
+    o = run_oracle(fx, torch.float64)
+    lv, pg, dg = res["fused"]
+    e_loss = abs(lv - float(o["loss"])) / abs(float(o["loss"]))
+    e_planes = [hp.rel_err(a.cpu().numpy(), b.grad.numpy()) for a, b in zip(pg, hp.flat_planes(o["planes"]))]
+    e_dec = {k: hp.rel_err(g.cpu().numpy(), (o["params"][k].grad if k != "beta" else o["beta"].grad).numpy()) for k, g in dg.items()
+             if k != "beta" or bool(fx["beta_is_param"])}
+    cos = [float((a.cpu().double().flatten() @ b.grad.flatten()) / (a.cpu().double().norm() * b.grad.norm() + 1e-300))
+           for a, b in zip(pg, hp.flat_planes(o["planes"]))]
+    print(f"mixed-precision training step vs float64 oracle: loss rel {e_loss:.2e}; plane gradients max-normalised error "
+          f"{max(e_planes):.2e} (geometry {max(e_planes[:6]):.2e}, colour {max(e_planes[6:]):.2e}), cosine >= {min(cos):.6f}; "
+          f"decoder gradients {max(e_dec.values()):.2e} ({max(e_dec, key=e_dec.get)})")
+    # measured on MI355X: loss 2.5e-5, plane gradients 3.2e-3 (cosine 0.999997), decoder gradients 4.0e-3
+    assert e_loss < 2e-4
+    assert max(e_planes) < 1e-2 and min(cos) > 0.9999
+    assert max(e_dec.values()) < 1.2e-2
 
 
 def test_multi_camera_batch_against_oracle():

@@ -48,6 +48,20 @@ for name, scene, R, ns, ni, zf in (("room0_4096x64", "room0", 4096, 56, 8, 0.0),
         row["nchw_graph_ms"] = round(timed(gn), 4)
         row["nchw_kernels_us"] = kernel_profile(wn.step)
         del gn, wn
+    if name == "freiburg_5000x56":
+        # BASELINE.json configs[4]: the same iteration on the mixed-precision kernels (fp16 plane copies, bf16 MFMA both ways)
+        from myslam_amd import lowp, ops
+        half = lowp.HalfPlanes(wl.planes)
+        def lp_step():
+            with ops.mixed_precision(half):
+                return wl.step()
+        for _ in range(5): lp_step()
+        row["lowp_kernels_us"] = kernel_profile(lp_step)
+        gl = harness.GraphedStep(lp_step, wl.params())
+        row["lowp_graph_ms"] = round(timed(gl), 4)
+        row["lowp_rs_per_s"] = wl.R * wl.S / row["lowp_graph_ms"] * 1e3
+        row["lowp_refresh_ms"] = round(timed(lambda: half.refresh(wl.planes)), 4)
+        del gl
     print(json.dumps(row), flush=True)
     del wl
     torch.cuda.empty_cache()
