@@ -9,15 +9,7 @@
 #include <stdlib.h>
 #include "eslam_decode_tile.h"
 #include "eslam_loss_final.h"
-
-#define SLAB 1364          // floats per decoder per wave slab (rgb decoder needs 1363)
-// offsets inside a per-decoder slab
-#define SL_W1 0
-#define SL_B1 1024
-#define SL_W2 1040
-#define SL_B2 1296
-#define SL_W3 1312         // [nout][16], nout <= 3
-#define SL_B3 1360         // [nout]
+#include "eslam_dec_reduce.h"
 
 // ---------------------------------------------------------------------------------------------------------
 // composite backward (autograd of reference src/utils/Renderer.py:140-153), one 64-sample chunk of one ray, sample role
@@ -480,57 +472,11 @@ __global__ __launch_bounds__(1024) void beta_sum_kernel(const float* __restrict_
     }
 }
 
-// slabs [nrows][2][SLAB] -> g_dec (flat, order of eslam_decoders_t).  grid (ceil(SLAB/64), 2), block 1024 =
-// 64 columns x 16 row groups; every thread keeps 8 independent loads in flight (the first version walked 512 rows
-// with one load outstanding and took 0.19 ms for 22 MB).
-#define RED_PARTS 16
-__global__ __launch_bounds__(1024) void dec_grad_reduce_kernel(const float* __restrict__ slabs, int nrows,
-                                                               float* __restrict__ g_dec,
-                                                               const float* __restrict__ beta_parts, int n_beta_parts,
-                                                               float* __restrict__ g_beta) {
-    __shared__ float red[RED_PARTS][64];
-    if (blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && beta_parts && g_beta) {
-        // the last column block has only 20 live columns: it also sums the g_beta partials
-        __shared__ float bsum[16];
-        float a = 0.f;
-        for (int i = threadIdx.x; i < n_beta_parts; i += 1024) a += beta_parts[i];
-        a = wave_sum(a);
-        if ((threadIdx.x & 63) == 0) bsum[threadIdx.x >> 6] = a;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            float t = 0.f;
-            for (int k = 0; k < 16; ++k) t += bsum[k];
-            g_beta[0] = t;
-        }
-    }
-    const int d = blockIdx.y;
-    const int cl = threadIdx.x & 63;
-    const int col = blockIdx.x * 64 + cl;
-    const int part = threadIdx.x >> 6;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (col < SLAB) {
-        const float* src = slabs + (int64_t)d * SLAB + col;
-        int row = part;
-        for (; row + 7 * RED_PARTS < nrows; row += 8 * RED_PARTS) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] += src[(int64_t)(row + u * RED_PARTS) * 2 * SLAB];
-        }
-        for (; row < nrows; row += RED_PARTS) acc[0] += src[(int64_t)row * 2 * SLAB];
-    }
-    red[part][cl] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-    __syncthreads();
-    if (part == 0 && col < SLAB) {
-        float v = 0.f;
-#pragma unroll
-        for (int k = 0; k < RED_PARTS; ++k) v += red[k][cl];
-        const int nout = d ? 3 : 1;
-        // slab offset -> flat offset inside the decoder's parameter block
-        int dst = -1;
-        if (col < SL_W3) dst = col;                                   // W1,b1,W2,b2 are laid out identically
-        else if (col < SL_W3 + nout * 16) dst = 1312 + (col - SL_W3);
-        else if (col >= SL_B3 && col < SL_B3 + nout) dst = 1312 + nout * 16 + (col - SL_B3);
-        if (dst >= 0) g_dec[(d ? 1329 : 0) + dst] = v;
-    }
+// slabs [nrows][2][SLAB] -> g_dec: eslam_dec_reduce.h.  Stand-alone launch, used when the scatter cannot carry the work
+// (no plane gradients requested, deterministic mode, free points).
+__global__ __launch_bounds__(1024) void dec_grad_reduce_kernel(const DecReduceArgs a) {
+    __shared__ float red[16 * 64];
+    dec_grad_reduce_block<1024>(a, blockIdx.x, blockIdx.y, red);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -677,7 +623,8 @@ static Bound make_bound(const float* b6) {
 
 int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float* rays_o, const float* rays_d,
                      const float* z_or_pts, int64_t R, int S, bool render, const float* g_feat, const int* perm,
-                     hipStream_t st, unsigned* records, int phase);
+                     hipStream_t st, unsigned* records, int phase, const DecReduceArgs* red);
+bool eslam_scatter_can_reduce(bool render, int phase);
 
 
 static int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
@@ -692,27 +639,6 @@ extern "C" int64_t eslam_bwd_workspace_bytes(int64_t n_points) {
     if (n_points < 0) return -1;
     return align256(n_points * 4 * 4) + align256(n_points * 128 * 4) +
            align256(slab_region_bytes(n_points)) + align256(n_points * 4);
-}
-
-// One auxiliary stream + two events per process, created on first use (i.e. in the caller's warm-up, never inside a
-// graph capture).  Off by default: measured on MI355X the fork/join made the step 1.7 % slower (0.474 vs 0.466 ms) -
-// the reduce kernel then competes with the scatter instead of filling an idle gap.  ESLAM_AUX_STREAM=1 enables it.
-struct AuxStream {
-    hipStream_t stream;
-    hipEvent_t fork, join;
-};
-static AuxStream* aux_stream() {
-    static AuxStream a;
-    static int state = 0;                 // 0 untried, 1 ready, -1 unavailable
-    if (state == 0) {
-        state = -1;
-        if (getenv("ESLAM_AUX_STREAM") &&
-            hipStreamCreateWithFlags(&a.stream, hipStreamNonBlocking) == hipSuccess &&
-            hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&a.join, hipEventDisableTiming) == hipSuccess)
-            state = 1;
-    }
-    return state == 1 ? &a : nullptr;
 }
 
 // mode 0: free points (g_o in the workspace); 1: rays, upstream gradients in rb; 2: rays, mapping-loss gradients from li
@@ -753,38 +679,6 @@ static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, 
     eslam_prof_end(PROF_MLP_BWD, st);
     if (int rc = eslam_check_launch("mlp_bwd_kernel")) return rc;
     const int n_beta_parts = render ? nwg : 0;
-    AuxStream* aux = nullptr;
-    if (g_dec) {
-    // The slab reduction (44 workgroups, latency-bound, ~16 us) does not depend on the scatter and the scatter does not
-    // depend on it: fork it onto the library's auxiliary stream and join at the end of the call (event fork/join, which
-    // a hipGraph capture of the caller's stream follows).
-    aux = aux_stream();
-    hipStream_t rs = st;
-    if (aux) {
-        if (hipEventRecord(aux->fork, st) != hipSuccess || hipStreamWaitEvent(aux->stream, aux->fork, 0) != hipSuccess) {
-            eslam_set_error("eslam_render_bwd: stream fork failed");
-            return 2;
-        }
-        rs = aux->stream;
-    }
-    eslam_prof_begin(PROF_DEC_REDUCE, rs);
-    hipLaunchKernelGGL(dec_grad_reduce_kernel, dim3((SLAB + 63) / 64, 2), dim3(1024), 0, rs, slabs, nwg, g_dec,
-                       render ? beta_parts : (const float*)nullptr, n_beta_parts, g_beta);
-    eslam_prof_end(PROF_DEC_REDUCE, rs);
-    if (int rc = eslam_check_launch("dec_grad_reduce_kernel")) return rc;
-    if (aux && hipEventRecord(aux->join, rs) != hipSuccess) {
-        eslam_set_error("eslam_render_bwd: stream join record failed");
-        return 2;
-    }
-    } else {
-        aux = nullptr;
-        if (g_beta && render) {      // beta's gradient does not go through the decoders: still sum its partials
-            hipLaunchKernelGGL(beta_sum_kernel, dim3(1), dim3(1024), 0, st, beta_parts, n_beta_parts, g_beta);
-            if (int rc = eslam_check_launch("beta_sum_kernel")) return rc;
-        }
-    }
-
-    // plane gradients
     bool any_grad = false, all_grad = true;
     for (int i = 0; i < NPL; ++i) {
         any_grad |= planes[i].grad != nullptr;
@@ -794,10 +688,28 @@ static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, 
         eslam_set_error("plane gradients must be requested for all 12 planes or for none");
         return 1;
     }
+    DecReduceArgs red = {};
+    red.slabs = slabs; red.nrows = nwg; red.g_dec = g_dec;
+    red.beta_parts = render ? beta_parts : nullptr; red.n_beta_parts = n_beta_parts; red.g_beta = g_beta;
+    // The slab reduction (44 workgroups, latency-bound, ~7 us as a launch of its own) rides in the scatter's grid when there
+    // is one: its workgroups run beside the scatter's first ones instead of in front of them.
+    const int phase = scatter_records ? 2 : 0;
+    const bool fold = g_dec && any_grad && eslam_scatter_can_reduce(render, phase);
+    if (g_dec && !fold) {
+        eslam_prof_begin(PROF_DEC_REDUCE, st);
+        hipLaunchKernelGGL(dec_grad_reduce_kernel, dim3(DEC_RED_COLBLOCKS, 2), dim3(1024), 0, st, red);
+        eslam_prof_end(PROF_DEC_REDUCE, st);
+        if (int rc = eslam_check_launch("dec_grad_reduce_kernel")) return rc;
+    } else if (!g_dec && g_beta && render) {      // beta's gradient does not go through the decoders: still sum its partials
+        hipLaunchKernelGGL(beta_sum_kernel, dim3(1), dim3(1024), 0, st, beta_parts, n_beta_parts, g_beta);
+        if (int rc = eslam_check_launch("beta_sum_kernel")) return rc;
+    }
+
+    // plane gradients
     if (any_grad) {
         eslam_prof_begin(PROF_SCATTER, st);
         if (int rc = eslam_scatter_v2(planes, bnd, rays_o, rays_d, z_or_pts, R, S, render, g_feat, perm, st,
-                                      (unsigned*)scatter_records, scatter_records ? 2 : 0))
+                                      (unsigned*)scatter_records, phase, fold ? &red : nullptr))
             return rc;
         eslam_prof_end(PROF_SCATTER, st);
     }
@@ -816,10 +728,6 @@ static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, 
 #undef LAUNCH
         eslam_prof_end(PROF_COORD_BWD, st);
         if (int rc = eslam_check_launch("coord_bwd_kernel")) return rc;
-    }
-    if (aux && hipStreamWaitEvent(st, aux->join, 0) != hipSuccess) {
-        eslam_set_error("eslam_render_bwd: stream join failed");
-        return 2;
     }
     return 0;
 }

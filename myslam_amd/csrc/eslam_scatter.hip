@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "eslam_decode_tile.h"
+#include "eslam_dec_reduce.h"
 
 #define SORT_MAX 8192
 typedef float float2_t __attribute__((ext_vector_type(2)));
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
                                                           const float* __restrict__ g_feat, int bundle,
                                                           int allow_counting, int nbundles, int xcd_map,
                                                           unsigned* __restrict__ records, long long* __restrict__ shadow,
-                                                          const ShadowOff shoff) {
+                                                          const ShadowOff shoff, const DecReduceArgs red, const int red_blocks) {
     constexpr int dbg_mode = DBG;
     constexpr int BM = 4 * NT;
     constexpr int SLOT_BITS = (BM == 1024) ? 10 : 11;
@@ -308,16 +309,25 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
     // g_feat row of the bundle; g_feat (134 MB) does not stay in a 4 MB L2, so those three workgroups are made
     // neighbours in time on ONE XCD (workgroups are dealt round-robin over the 8 XCDs, each with its own L2): with the
     // plain (bundle, plane) grid 81 % of the walk's row reads missed L2.
+    // The first red_blocks workgroups (a multiple of 8, so that the XCD dealing below is unchanged) are not scatter workgroups:
+    // they sum the decoder-gradient slabs of the decoder backward that ran just before (eslam_dec_reduce.h), beside the
+    // scatter's first workgroups instead of as a launch of their own in front of them.
+    if (red_blocks > 0 && (int)blockIdx.x < red_blocks) {
+        if ((int)blockIdx.x < 2 * DEC_RED_COLBLOCKS)
+            dec_grad_reduce_block<NT>(red, blockIdx.x % DEC_RED_COLBLOCKS, blockIdx.x / DEC_RED_COLBLOCKS, (float*)lds_raw);
+        return;
+    }
+    const int bid = (int)blockIdx.x - red_blocks;
     int bidx, pi;
     if (xcd_map) {
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int xcd = bid & 7, j = bid >> 3;
         const int q = (j / 3) * 8 + xcd;                     // (bundle, segment) pair handled by this XCD slot
         if (q >= nbundles * 4) return;
         const int seg = q & 3;                               // decoder * 2 + level
         bidx = q >> 2;
         pi = (seg >> 1) * 6 + (j % 3) * 2 + (seg & 1);
     } else {
-        bidx = blockIdx.x;
+        bidx = bid;
         pi = blockIdx.y;                                     // plane index in all_planes order
     }
     const int d = pi / 6, o = (pi % 6) >> 1, lvl = pi & 1;
@@ -818,10 +828,18 @@ extern "C" int64_t eslam_scatter_records_bytes(int R, int S) {
     return nbundles * NPL * (6 * (int64_t)bm + REC_META) * 4;
 }
 
+// whether the scatter launch of this mode can also run the decoder-gradient slab reduction (the production render path: one
+// kernel, XCD-mapped 1-D grid, 512 threads); the stand-alone dec_grad_reduce_kernel covers the rest
+bool eslam_scatter_can_reduce(bool render, int phase) {
+    static const int xcd_map = env_int("ESLAM_SC_XCDMAP", 1), dbg_mode = env_int("ESLAM_SC_MODE", 0), bm = env_int("ESLAM_SC_BUNDLE", 2048);
+    static const int off = env_int("ESLAM_SC_NO_REDUCE", 0);
+    return render && phase == 0 && !eslam_deterministic() && xcd_map && dbg_mode == 0 && bm != 1024 && !off;
+}
+
 // phase 0: cells + sort + walk; 1: cells + sort -> records (g_feat unused); 2: walk of the records
 int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float* rays_o, const float* rays_d,
                      const float* z_or_pts, int64_t R, int S, bool render, const float* g_feat, const int* perm,
-                     hipStream_t st, unsigned* records, int phase) {
+                     hipStream_t st, unsigned* records, int phase, const DecReduceArgs* red) {
     PlaneSet ps;
     for (int i = 0; i < NPL; ++i) {
         ps.p[i] = planes[i];
@@ -859,9 +877,21 @@ int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float*
     const int nbundles = (nunits + bundle - 1) / bundle;
     dim3 grid(nbundles, NPL);
     if (xcd_map) grid = dim3(((nbundles * 4 + 7) / 8) * 8 * 3, 1);
+    DecReduceArgs red_args = {};
+    int red_blocks = 0;
+    if (red) {
+        if (!eslam_scatter_can_reduce(render, phase)) {
+            eslam_set_error("scatter: cannot carry the decoder-gradient reduction in this mode");
+            return 1;
+        }
+        red_args = *red;
+        red_blocks = (2 * DEC_RED_COLBLOCKS + 7) / 8 * 8;
+        grid.x += red_blocks;
+    }
 #define LAUNCH_SC(RD, DB, NTv, PH, PERM, SS)                                                                               \
     hipLaunchKernelGGL((scatter_sort_kernel<RD, DB, NTv, PH, false>), grid, dim3(NTv), 0, st, ps, bnd, rays_o, rays_d, z_or_pts, \
-                       PERM, (int)R, SS, g_feat, bundle, counting, nbundles, xcd_map, records, (long long*)nullptr, ShadowOff{})
+                       PERM, (int)R, SS, g_feat, bundle, counting, nbundles, xcd_map, records, (long long*)nullptr, ShadowOff{}, \
+                       red_args, red_blocks)
     if (phase != 0 && (!render || !records)) {
         eslam_set_error("scatter: record phases need render mode and a record buffer");
         return 1;
@@ -900,11 +930,12 @@ int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float*
         }
         if (render)
             hipLaunchKernelGGL((scatter_sort_kernel<true, 0, 512, 0, true>), grid, dim3(512), 0, st, ps, bnd, rays_o, rays_d,
-                               z_or_pts, perm, (int)R, S, g_feat, bundle, counting, nbundles, xcd_map, (unsigned*)nullptr, shadow, so);
+                               z_or_pts, perm, (int)R, S, g_feat, bundle, counting, nbundles, xcd_map, (unsigned*)nullptr, shadow, so,
+                               DecReduceArgs{}, 0);
         else
             hipLaunchKernelGGL((scatter_sort_kernel<false, 0, 512, 0, true>), grid, dim3(512), 0, st, ps, bnd, rays_o, rays_d,
                                z_or_pts, (const int*)nullptr, (int)R, 64, g_feat, bundle, counting, nbundles, xcd_map,
-                               (unsigned*)nullptr, shadow, so);
+                               (unsigned*)nullptr, shadow, so, DecReduceArgs{}, 0);
         if (int rc = eslam_check_launch("scatter_sort_kernel<det>")) return rc;
         for (int i = 0; i < NPL; ++i) {
             const int64_t numel = (int64_t)ESLAM_C_DIM * planes[i].h * planes[i].w;
@@ -946,7 +977,7 @@ extern "C" int eslam_scatter_prep(const eslam_plane_t* planes, const float* boun
     Bound bnd;
     for (int k = 0; k < 3; ++k) { bnd.lo[k] = bound6_host[2 * k]; bnd.hi[k] = bound6_host[2 * k + 1]; }
     return eslam_scatter_v2(planes, bnd, rays_o, rays_d, z_vals, R, S, true, nullptr, (const int*)ray_order,
-                            (hipStream_t)stream, (unsigned*)records, 1);
+                            (hipStream_t)stream, (unsigned*)records, 1, nullptr);
 }
 
 int eslam_scatter_v2_init() {
