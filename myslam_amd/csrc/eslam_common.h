@@ -52,6 +52,25 @@ __device__ __forceinline__ void stage_decoder_weights(float* lds, const eslam_de
     }
 }
 
+// one decoder only (the importance sampler needs the SDF decoder alone), at lds[0 .. DEC_LDS)
+__device__ __forceinline__ void stage_decoder_weights_one(float* L, const eslam_decoders_t& dec, int d, int tid, int nthreads) {
+    const float* w1 = d ? dec.cw1 : dec.w1;
+    const float* b1 = d ? dec.cb1 : dec.b1;
+    const float* w2 = d ? dec.cw2 : dec.w2;
+    const float* b2 = d ? dec.cb2 : dec.b2;
+    const float* w3 = d ? dec.cw3 : dec.w3;
+    const float* b3 = d ? dec.cb3 : dec.b3;
+    const int nout = d ? 3 : 1;
+    for (int i = tid; i < 1024; i += nthreads) L[DEC_W1 + i] = w1[i];
+    for (int i = tid; i < 256; i += nthreads) L[DEC_W2 + i] = w2[i];
+    for (int i = tid; i < 16; i += nthreads) {
+        L[DEC_B1 + i] = b1[i];
+        L[DEC_B2 + i] = b2[i];
+    }
+    for (int i = tid; i < 64; i += nthreads) L[DEC_W3 + i] = (i < nout * 16) ? w3[i] : 0.0f;
+    for (int i = tid; i < 4; i += nthreads) L[DEC_B3 + i] = (i < nout) ? b3[i] : 0.0f;
+}
+
 // normalize_3d_coordinate (reference src/common.py:215-217), same operation order.
 __device__ __forceinline__ float norm_coord(float p, float lo, float hi) {
     return __fsub_rn(__fmul_rn(__fdiv_rn(__fsub_rn(p, lo), __fsub_rn(hi, lo)), 2.0f), 1.0f);

@@ -258,8 +258,12 @@ __global__ __launch_bounds__(256) void sample_z_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------------------
 // K4: reference src/utils/Renderer.py:108-134 + src/common.py:41-77.  One wave per zero-depth ray.
 // ---------------------------------------------------------------------------------------------------------
-// WITH_DEPTH: the same launch also produces the rows of the rays WITH depth (K3) before it looks for depth-less ones -
-// one launch instead of two for the whole z_vals tensor (most batches have no depth-less ray and leave right after).
+// ONE WORKGROUP PER RAY.  A ray with depth (WITH_DEPTH: the same launch also produces those rows, K3) is one wave's job
+// and the other three leave at once; a depth-less ray is worked on by all four waves: the SDF decode of its n_strat
+// points - a chain of 6 dependent gather + MLP blocks at n_strat = 88 when one wave did it alone, 42 us of this kernel for a
+// 1024-ray ScanNet batch with 10 % depth-less rays - is dealt out block by block, then wave 0 inverts the cdf.
+// (Four rays per workgroup with the four waves taking the workgroup's depth-less rays one after the other was SLOWER, 76 us:
+// the kernel then lasts as long as its unluckiest workgroup, which holds two or three such rays.)
 template <bool CL, bool WITH_DEPTH>
 __global__ __launch_bounds__(256, 2) void importance_z_kernel(const PlaneSet planes, const eslam_decoders_t dec,
                                                            const Bound bnd, const float* __restrict__ rays_o,
@@ -272,83 +276,71 @@ __global__ __launch_bounds__(256, 2) void importance_z_kernel(const PlaneSet pla
                                                            const float* __restrict__ t_surf,
                                                            const float* __restrict__ t_rand, const RngArg rng_arg) {
     const Rng rng = make_rng(rng_arg);
-    __shared__ __attribute__((aligned(16))) float wlds[2 * DEC_LDS];
-    __shared__ float zu_all[4][ESLAM_MAX_SAMPLES];      // jittered uniform samples, then the merged list
-    __shared__ float wt_all[4][ESLAM_MAX_SAMPLES];      // weights -> cdf
-    __shared__ float zn_all[4][ESLAM_MAX_SAMPLES];      // importance samples
-    if (WITH_DEPTH) {
-        const int ray0 = blockIdx.x * 4 + (threadIdx.x >> 6);
-        if (ray0 < R) {
-            const float d0 = gt_depth[ray0];
-            if (d0 > 0.0f)
-                depth_guided_row(d0, ray0, n_strat, n_imp, c15, c3, t_free, t_surf, t_rand, z_vals,
-                                 zu_all[threadIdx.x >> 6], threadIdx.x & 63, rng);
-        }
-    }
-    {   // most batches have no depth-less ray at all: leave before the 11 KB of weights are staged
-        bool any = false;
-        for (int w = 0; w < 4; ++w) {
-            const int rr = blockIdx.x * 4 + w;
-            any |= (rr < R) && !(gt_depth[rr] > 0.0f);
-        }
-        if (!any) return;                                // uniform over the workgroup
-    }
-    stage_decoder_weights(wlds, dec, threadIdx.x, blockDim.x);
-    __syncthreads();
+    __shared__ __attribute__((aligned(16))) float wlds[DEC_LDS];          // the SDF decoder only
+    __shared__ float zu[ESLAM_MAX_SAMPLES];      // jittered uniform samples (depth rows: the rank merge's scratch)
+    __shared__ float wt[ESLAM_MAX_SAMPLES];      // uniform samples before the jitter, then weights -> cdf
+    __shared__ float zn[ESLAM_MAX_SAMPLES];      // importance samples
+    __shared__ float al[ESLAM_MAX_SAMPLES];      // alpha of the n_strat points
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ray = blockIdx.x;
+    const float d0 = gt_depth[ray];
+    if (d0 > 0.0f) {                                 // uniform over the workgroup
+        if (WITH_DEPTH && wave == 0)
+            depth_guided_row(d0, ray, n_strat, n_imp, c15, c3, t_free, t_surf, t_rand, z_vals, zu, lane, rng);
+        return;
+    }
+    stage_decoder_weights_one(wlds, dec, 0, threadIdx.x, blockDim.x);
     const int r = lane & 15, q = lane >> 4;                                  // MFMA role (eslam_decode_tile.h)
     const int gp = gather_point<CL>(lane), gq = gather_piece<CL>(lane);     // gather role
-    const int ray = blockIdx.x * 4 + wave;
-    if (ray >= R) return;
-    if (gt_depth[ray] > 0.0f) return;
-    float* zu = zu_all[wave];
-    float* wt = wt_all[wave];
-    float* zn = zn_all[wave];
+    const float beta = dec.beta[0];
+    const int S = n_strat + n_imp;
     const float o[3] = {rays_o[3 * ray], rays_o[3 * ray + 1], rays_o[3 * ray + 2]};
     const float d[3] = {rays_d[3 * ray], rays_d[3 * ray + 1], rays_d[3 * ray + 2]};
     const float far = __fadd_rn(aabb_exit_dev(o, d, bnd), 0.01f);          // Renderer.py:114-117
-    const float beta = dec.beta[0];
 
     // Renderer.py:119: near*(1-t) + far*t with near = 0
-    for (int i = lane; i < n_strat; i += WAVE) {
+    for (int i = threadIdx.x; i < n_strat; i += 256) {
         const float t = t_free[i];
         wt[i] = __fadd_rn(__fmul_rn(0.0f, __fsub_rn(1.0f, t)), __fmul_rn(far, t));
     }
-    WAVE_SYNC();
-    for (int i = lane; i < n_strat; i += WAVE)
+    __syncthreads();                                 // (also: the decoder weights are staged)
+    for (int i = threadIdx.x; i < n_strat; i += 256)
         zu[i] = t_rand_uni ? jitter_one(wt, i, n_strat, t_rand_uni[(int64_t)ray * n_strat + i])
                            : (rng.on && rng.perturb) ? jitter_one(wt, i, n_strat, rng_uniform(rng, 1u, (uint32_t)(ray * n_strat + i))) : wt[i];
-    WAVE_SYNC();
+    __syncthreads();
 
-    // SDF decode of the n_strat points (geometry planes only), alpha, transmittance, weights (Renderer.py:122-129)
+    // SDF decode of the n_strat points (geometry planes only) -> alpha (Renderer.py:122-127); wave w takes blocks w, w+4, ...
+    const int nblk = (n_strat + 15) >> 4;
+#pragma unroll 1
+    for (int b = wave; b < nblk; b += 4) {
+        const int oz0 = opaque_zero(b);
+        const float z = zu[min(16 * b + gp, n_strat - 1)];
+        // Renderer.py:122: o + d*z (mul then add, as torch does)
+        const float x = norm_coord(__fadd_rn(o[0], __fmul_rn(d[0], z)), bnd.lo[0], bnd.hi[0]);
+        const float y = norm_coord(__fadd_rn(o[1], __fmul_rn(d[1], z)), bnd.lo[1], bnd.hi[1]);
+        const float zz = norm_coord(__fadd_rn(o[2], __fmul_rn(d[2], z)), bnd.lo[2], bnd.hi[2]);
+        float feat[16];
+        gather_features<CL>(planes, 0, x, y, zz, gq, feat, oz0);
+        to_mfma_role<CL, 16>(feat, lane);
+        DecFrag f;
+        load_dec_frag(f, wlds + oz0, r, q);
+        float4_t h1, h2;
+        mlp_hidden(f, feat, h1, h2);
+        float4_t out = *(const float4_t*)(wlds + DEC_B3);
+        mlp_out_accum(f, h2, 0, r, out);             // rows 0..3 of the padded output layer: lanes 0..15 hold point 16b + lane
+        if (lane < 16 && 16 * b + lane < n_strat) {
+            const float sdf = tanhf(out[0]);
+            al[16 * b + lane] = 1.0f - expf(-beta * sigmoidf_(-sdf * beta));
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+
+    // transmittance and weights (Renderer.py:128-129), 64 samples at a time
     float trans_in = 1.0f;
     for (int c0 = 0; c0 < n_strat; c0 += WAVE) {
-        const int nvalid = min(WAVE, n_strat - c0);
-        const int nblk = (nvalid + 15) >> 4;
-        float4_t out = *(const float4_t*)(wlds + DEC_B3);
-#pragma unroll 1
-        for (int b = 0; b < nblk; ++b) {
-            {
-                const int oz0 = opaque_zero(b);
-                const float z = zu[min(c0 + 16 * b + gp, n_strat - 1)];
-                // Renderer.py:122: o + d*z (mul then add, as torch does)
-                const float x = norm_coord(__fadd_rn(o[0], __fmul_rn(d[0], z)), bnd.lo[0], bnd.hi[0]);
-                const float y = norm_coord(__fadd_rn(o[1], __fmul_rn(d[1], z)), bnd.lo[1], bnd.hi[1]);
-                const float zz = norm_coord(__fadd_rn(o[2], __fmul_rn(d[2], z)), bnd.lo[2], bnd.hi[2]);
-                float feat[16];
-                gather_features<CL>(planes, 0, x, y, zz, gq, feat, oz0);
-                to_mfma_role<CL, 16>(feat, lane);
-                DecFrag f;
-                load_dec_frag(f, wlds + oz0, r, q);
-                float4_t h1, h2;
-                mlp_hidden(f, feat, h1, h2);
-                mlp_out_accum(f, h2, b, r, out);
-            }
-        }
-        const bool valid = lane < nvalid;
-        const float sdf = tanhf(out[0]);
-        float alpha = 1.0f - expf(-beta * sigmoidf_(-sdf * beta));
-        if (!valid) alpha = 0.0f;
+        const bool valid = c0 + lane < n_strat;
+        const float alpha = valid ? al[c0 + lane] : 0.0f;
         const float fac = valid ? (1.0f - alpha) + 1e-10f : 1.0f;
         const float pin = wave_incl_prod(fac, lane);
         float pex = __shfl_up(pin, 1, WAVE);
@@ -389,7 +381,6 @@ __global__ __launch_bounds__(256, 2) void importance_z_kernel(const PlaneSet pla
     WAVE_SYNC();
 
     // Renderer.py:133: sort(cat(z_uni, z_samples)) as a stable rank sort (values are what matter)
-    const int S = n_strat + n_imp;
     float* out_row = z_vals + (int64_t)ray * S;
     for (int i = lane; i < S; i += WAVE) {
         const float v = (i < n_strat) ? zu[i] : zn[i - n_strat];
@@ -525,7 +516,7 @@ extern "C" int eslam_importance_z(const eslam_plane_t* planes, const eslam_decod
     PlaneSet ps;
     for (int i = 0; i < NPL; ++i) ps.p[i] = planes[i < 6 ? i : i - 6];
     const Bound bnd = make_bound(bound6_host);
-    dim3 grid((R + 3) / 4), block(256);
+    dim3 grid(R), block(256);            // one workgroup per ray
     eslam_prof_begin(PROF_IMPORTANCE_Z, (hipStream_t)stream);
     if (eslam_planes_channels_last(planes, 0, 6))
         hipLaunchKernelGGL((importance_z_kernel<true, false>), grid, block, 0, (hipStream_t)stream, ps, *dec, bnd, rays_o,
@@ -564,7 +555,7 @@ static int sample_z_all_impl(const char* who, const eslam_plane_t* planes, const
     const Bound bnd = make_bound(bound6_host);
     const float c15 = (float)(1.5 * truncation);       // as eslam_sample_z
     const float c3 = (float)(3.0 * truncation);
-    dim3 grid((R + 3) / 4), block(256);
+    dim3 grid(R), block(256);            // one workgroup per ray
     eslam_prof_begin(PROF_SAMPLE_Z, (hipStream_t)stream);
     if (eslam_planes_channels_last(planes, 0, 6))
         hipLaunchKernelGGL((importance_z_kernel<true, true>), grid, block, 0, (hipStream_t)stream, ps, *dec, bnd, rays_o,
