@@ -266,7 +266,7 @@ __global__ __launch_bounds__(1024) void ray_order_kernel(const float* __restrict
 //   planes; scatter_fixed_to_float_kernel then adds the shadow to the float gradients and clears it.
 #define FIX_SCALE 17592186044416.0f                  // 2^44: |contribution| < 5e5, resolution 5.7e-14
 struct ShadowOff { int64_t o[NPL]; };
-template <bool RENDER, int DBG, int NT, int PHASE, bool DET>
+template <bool RENDER, int DBG, int NT, int PHASE, bool DET, int SPT = 4>
 __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes, const Bound bnd,
                                                           const float* __restrict__ rays_o,
                                                           const float* __restrict__ rays_d,
@@ -277,7 +277,9 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
                                                           unsigned* __restrict__ records, long long* __restrict__ shadow,
                                                           const ShadowOff shoff, const DecReduceArgs red, const int red_blocks) {
     constexpr int dbg_mode = DBG;
-    constexpr int BM = 4 * NT;
+    constexpr int BM = SPT * NT;                       // SPT samples per thread in the cell / sort phases
+    constexpr int CH = WAVE * SPT;                     // sorted entries a wave walks
+    static_assert(SPT == 2 || SPT == 4, "samples per thread");
     constexpr int SLOT_BITS = (BM == 1024) ? 10 : 11;
     constexpr unsigned SLOT_MASK = BM - 1;
     static_assert(BM == 1024 || BM == 2048, "bundle size");
@@ -356,11 +358,11 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
     __syncthreads();
 
     // (1) bilinear cell of every sample of the bundle (4 per thread), and the bundle's bounding box in the plane
-    AxisCoord cax[4], cay[4];
-    int cpt[4];
+    AxisCoord cax[SPT], cay[SPT];
+    int cpt[SPT];
     int bx0 = 0x7FFFFFFF, bx1 = -1, by0 = 0x7FFFFFFF, by1 = -1;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < SPT; ++k) {
         const int slot = threadIdx.x + k * NT;
         cpt[k] = -1;
         if (slot < n) {
@@ -419,9 +421,9 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
         constexpr int WPT = 2 * BM / NT;                       // counter words per thread in the scan
         for (int i = threadIdx.x; i < 2 * BM; i += NT) cnt[i] = 0u;
         __syncthreads();
-        unsigned loc[4], tick[4];
+        unsigned loc[SPT], tick[SPT];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < SPT; ++k) {
             loc[k] = 0; tick[k] = 0;
             if (cpt[k] >= 0) {
                 const int im = swap ? cay[k].i0 : cax[k].i0, iM = swap ? cax[k].i0 : cay[k].i0;
@@ -458,12 +460,12 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
             run += lo16 + hi16;
         }
         __syncthreads();
-        unsigned pos[4];
+        unsigned pos[SPT];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) pos[k] = ((cnt[loc[k] >> 1] >> ((loc[k] & 1u) * 16u)) & 0xFFFFu) + tick[k];
+        for (int k = 0; k < SPT; ++k) pos[k] = ((cnt[loc[k] >> 1] >> ((loc[k] & 1u) * 16u)) & 0xFFFFu) + tick[k];
         __syncthreads();                                       // counters are dead: their memory becomes stm / stM
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < SPT; ++k) {
             if (cpt[k] >= 0) {
                 const AxisCoord& am = swap ? cay[k] : cax[k];
                 const AxisCoord& aM = swap ? cax[k] : cay[k];
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
         __syncthreads();
     } else {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < SPT; ++k) {
         const int slot = threadIdx.x + k * NT;
         unsigned key = 0xFFFFFFFFu;
         if (cpt[k] >= 0) {
@@ -504,13 +506,13 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
     // [256w, 256w+256): every compare-exchange distance j < 256 stays inside one wave's chunk and needs no workgroup
     // barrier (DS operations of a wave execute in order); only the stages with j >= 256 synchronise the workgroup.
     {
-        const int wbase = wave * 256;
+        const int wbase = wave * CH;
         for (int k = 2; k <= BM; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
-                if (j >= 256) {
+                if (j >= CH) {
                     __syncthreads();
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
+                    for (int t = 0; t < SPT / 2; ++t) {
                         const int p = threadIdx.x + t * NT;                       // pair index
                         const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));      // lower element of the pair
                         const int l = i | j;
@@ -520,7 +522,7 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
                     __syncthreads();
                 } else {
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
+                    for (int t = 0; t < SPT / 2; ++t) {
                         const int p = lane + t * WAVE;                            // pair index inside the wave's chunk
                         const int i = wbase + (((p & ~(j - 1)) << 1) | (p & (j - 1)));
                         const int l = i | j;
@@ -534,11 +536,11 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
     }
     // records into sorted order, through registers (the temporaries and the final layout overlap)
     __syncthreads();
-    unsigned pxy[4];
-    float ptm[4], ptM[4];
-    int prow[4];
+    unsigned pxy[SPT];
+    float ptm[SPT], ptM[SPT];
+    int prow[SPT];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < SPT; ++k) {
         const unsigned key = skey[threadIdx.x + k * NT];
         const bool valid = key != 0xFFFFFFFFu;
         const int slot = key & SLOT_MASK;
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < SPT; ++k) {
         const int q = threadIdx.x + k * NT;
         const bool valid = pxy[k] != PAD_XY;
         sxy[q] = pxy[k];
@@ -581,7 +583,7 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
     unsigned last_xy = PAD_XY;                 // xy of the last entry of the previous block
     typedef typename std::conditional<DET, long long, float>::type acc_t;
     acc_t acc0 = 0, acc1 = 0;
-    const int e0 = wave * 256;
+    const int e0 = wave * CH;
 
     // Flush of a finished cell: lane (hx, c) adds its two sums (major-axis corners 0 and 1) for its minor-axis corner.
     // All addressing is 32-bit VALU arithmetic on a byte offset from the wave-uniform plane base (SGPR base + VGPR
@@ -659,7 +661,7 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
         }                                                                                     \
     }
 
-    const int nblk = 256 / WAVE;
+    const int nblk = CH / WAVE;
     const int ngrp = WAVE / WALK_N;                 // groups per 64-entry record block (even)
     float ga[WALK_N], gb[WALK_N];
     Rec rec = fetch(0, PAD_XY);
@@ -874,6 +876,7 @@ int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float*
         }
     static const int counting = env_int("ESLAM_SC_COUNTING", 1);   // A/B switch: 0 = always the bitonic network
     static const int xcd_map = env_int("ESLAM_SC_XCDMAP", 1);      // A/B switch: 0 = plain (bundle, plane) grid
+    static const int wide = env_int("ESLAM_SC_WIDE", 0);           // 1024 threads x 2 samples: a wave walks 128 entries, not 256
     const int nbundles = (nunits + bundle - 1) / bundle;
     dim3 grid(nbundles, NPL);
     if (xcd_map) grid = dim3(((nbundles * 4 + 7) / 8) * 8 * 3, 1);
@@ -950,7 +953,11 @@ int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float*
         else if (dbg_mode == 1) LAUNCH_SC(true, 1, 512, 0, perm, S);
         else if (dbg_mode == 2) LAUNCH_SC(true, 2, 512, 0, perm, S);
         else if (bm == 1024) LAUNCH_SC(true, 0, 256, 0, perm, S);
-        else LAUNCH_SC(true, 0, 512, 0, perm, S);
+        else if (wide) {
+            hipLaunchKernelGGL((scatter_sort_kernel<true, 0, 1024, 0, false, 2>), grid, dim3(1024), 0, st, ps, bnd, rays_o, rays_d,
+                               z_or_pts, perm, (int)R, S, g_feat, bundle, counting, nbundles, xcd_map, records, (long long*)nullptr,
+                               ShadowOff{}, red_args, red_blocks);
+        } else LAUNCH_SC(true, 0, 512, 0, perm, S);
     } else {
         LAUNCH_SC(false, 0, 512, 0, (const int*)nullptr, 64);
     }
