@@ -253,7 +253,8 @@ __global__ __launch_bounds__(1024) void ray_order_kernel(const float* __restrict
 // bundle scatter
 // ---------------------------------------------------------------------------------------------------------
 // NT threads per workgroup, BM = 4*NT samples per workgroup (power of two).
-//   DBG: 0 production; 1 walk without atomics; 2 stop after the sort (profiling only, tools/dbg_scatter.py)
+//   DBG: 0 production; 1 walk without atomics; 2 stop after the sort; 3 = 1 without the g_feat row loads; 4 = 3 without the
+//   LDS weight reads (profiling only, tools/scatter_anatomy.sh)
 //   PHASE: 0 = cells + sort + walk in one launch.  The cells and the sort depend on the sample POSITIONS only, not on the
 //   feature gradients, so they can run long before the backward pass, beside the forward kernel on another stream:
 //   PHASE 1 (eslam_scatter_prep) stops after the sort and writes the workgroup's sorted record image (the 6*BM words of
@@ -601,7 +602,7 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
                     atomicAdd((unsigned long long*)(gbytes + 2 * (size_t)o0), (unsigned long long)acc0);
                     atomicAdd((unsigned long long*)(gbytes + 2 * (size_t)o1), (unsigned long long)acc1);
                 }
-            } else if (dbg_mode != 1) {
+            } else if (dbg_mode == 0) {
                 if (!lower_half_only || hx == 0) {
                     atomicAdd((float*)(gbytes + o0), (float)acc0);
                     atomicAdd((float*)(gbytes + o1), (float)acc1);
@@ -631,12 +632,12 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
 #define LOAD_HALF(buf, rec, half)                                                             \
     _Pragma("unroll") for (int t = 0; t < WALK_N; ++t) {                                      \
         const unsigned row = (unsigned)__builtin_amdgcn_readlane((rec).row, (half) * WALK_N + t); \
-        buf[t] = *(const float*)(gcol + (row * 512u + (unsigned)c * 4u));                     \
+        buf[t] = (dbg_mode >= 3) ? __uint_as_float(row) : *(const float*)(gcol + (row * 512u + (unsigned)c * 4u)); \
     }
 #define WALK_HALF(buf, rec, half, ebase)                                                      \
     _Pragma("unroll") for (int t = 0; t < WALK_N; ++t) {                                      \
         const int idx = (half) * WALK_N + t;                                                  \
-        const float2_t w2 = wlane[2 * ((ebase) + idx)];                                       \
+        const float2_t w2 = (dbg_mode == 4) ? (float2_t){1.f, 2.f} : wlane[2 * ((ebase) + idx)]; \
         if (((rec).fresh >> idx) & 1ull) {                                                    \
             if (((rec).adjacent >> idx) & 1ull) {                                             \
                 /* next cell along the minor axis: its first texel column is our second one - keep those sums */ \
@@ -952,6 +953,8 @@ int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float*
         else if (phase == 2) { if (bm == 1024) LAUNCH_SC(true, 0, 256, 2, perm, S); else LAUNCH_SC(true, 0, 512, 2, perm, S); }
         else if (dbg_mode == 1) LAUNCH_SC(true, 1, 512, 0, perm, S);
         else if (dbg_mode == 2) LAUNCH_SC(true, 2, 512, 0, perm, S);
+        else if (dbg_mode == 3) LAUNCH_SC(true, 3, 512, 0, perm, S);
+        else if (dbg_mode == 4) LAUNCH_SC(true, 4, 512, 0, perm, S);
         else if (bm == 1024) LAUNCH_SC(true, 0, 256, 0, perm, S);
         else if (wide) {
             hipLaunchKernelGGL((scatter_sort_kernel<true, 0, 1024, 0, false, 2>), grid, dim3(1024), 0, st, ps, bnd, rays_o, rays_d,
