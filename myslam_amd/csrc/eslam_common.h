@@ -114,7 +114,9 @@ __device__ __forceinline__ AxisCoord axis_coord(float u, int n) {
 // A wave-uniform zero the optimiser cannot fold (used to pin scalar loads inside loops, see gather_features).
 __device__ __forceinline__ int opaque_zero(int loop_var) {
     int z = __builtin_amdgcn_readfirstlane(loop_var);
-    asm volatile("s_and_b32 %0, %0, 0" : "+s"(z));
+    // s_and_b32 writes SCC: without the clobber the compiler may keep a comparison result live in SCC across this statement
+    // (it did, once: a `last ? 0 : b + 1` next to it selected the wrong arm in one of two unrolled copies of a loop)
+    asm volatile("s_and_b32 %0, %0, 0" : "+s"(z) : : "scc");
     return z;
 }
 

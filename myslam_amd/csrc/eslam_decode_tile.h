@@ -198,7 +198,45 @@ __device__ __forceinline__ void gather_features(const PlaneSet& planes, int d, f
     }
 }
 
+// The same gather for a wave that decodes one 16-point block after the other (channels-last planes): plane 0 of the NEXT
+// block is requested before this block's features are stored and its MLP runs.  `carry` holds plane 0 of this block, in
+// flight, on entry, and plane 0 of block (dn, xn, yn, zn) on return (the last block of a tile requests the tile's first
+// block again, unused: a branch around 8 of 384 loads costs more than they do).  Without it every block started with
+// an exposed texel latency, and - a wave's loads and stores retire in order on one vmcnt counter - its first wait also
+// waited for the previous block's four feature stores.
+__device__ __forceinline__ void issue_plane0(const PlaneSet& planes, int d, float x, float y, float z, int q, int opaque0,
+                                             PlaneTaps& t) {
+    issue_taps(planes.p[6 * d + opaque0], ORIENT_U(0, x, y, z), ORIENT_V(0, x, y, z), q, t);
+}
+
+__device__ __forceinline__ void gather_features_chain(const PlaneSet& planes, int d, float x, float y, float z, int q,
+                                                      float feat[16], int opaque0, PlaneTaps& carry, int dn, float xn, float yn,
+                                                      float zn) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) feat[i] = 0.0f;
+    PlaneTaps odd;                         // planes 1, 3, 5; planes 0, 2, 4 use `carry`
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int kn = k + 1;
+        if (kn < 6) {
+            issue_taps(planes.p[2 * (3 * d + (kn % 3)) + (kn / 3) + opaque0], ORIENT_U(kn % 3, x, y, z),
+                       ORIENT_V(kn % 3, x, y, z), q, (kn & 1) ? odd : carry);
+        } else {
+            issue_plane0(planes, dn, xn, yn, zn, q, opaque0, carry);
+        }
+        accumulate_taps((k & 1) ? odd : carry, feat + 8 * (k / 3));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // store the lane's 16 features (piece q of both levels) of decoder d for point `pt` into feat_out [N,128]
+// NT: streaming (non-temporal) stores for the features a forward pass saves (134 MB at 4096 x 64, read back once, by the
+// backward pass): they no longer displace plane texels from the XCD's 4 MB L2 on their way out.  Measured at 4096 x 64 /
+// 8192 x 96: forward 92 -> 89 / 234 -> 218 us, and the kernels behind it gain too (decoder backward 80 -> 74 / 215 -> 204,
+// scatter 118 -> 113 / 305 -> 292).  Non-temporal LOADS of the features in the backward pass (+2 / +25 us there) and
+// non-temporal stores of the feature GRADIENTS, which three scatter workgroups re-read through L2 (+8 us in the scatter),
+// were measured and dropped (profiles/r02/n_*).
+template <bool NT = false>
 __device__ __forceinline__ void store_features(float* feat_out, int64_t pt, int d, int q, const float feat[16]) {
     float* dst = feat_out + pt * 128 + d * 64 + 4 * q;
 #pragma unroll
@@ -209,8 +247,13 @@ __device__ __forceinline__ void store_features(float* feat_out, int64_t pt, int 
             a[i] = feat[lvl * 8 + i];
             b[i] = feat[lvl * 8 + 4 + i];
         }
-        *(float4_t*)(dst + lvl * 32) = a;
-        *(float4_t*)(dst + lvl * 32 + 16) = b;
+        if (NT) {
+            __builtin_nontemporal_store(a, (float4_t*)(dst + lvl * 32));
+            __builtin_nontemporal_store(b, (float4_t*)(dst + lvl * 32 + 16));
+        } else {
+            *(float4_t*)(dst + lvl * 32) = a;
+            *(float4_t*)(dst + lvl * 32 + 16) = b;
+        }
     }
 }
 
@@ -379,7 +422,7 @@ __device__ __forceinline__ void store_features_lp(float* feat_out, int64_t pt, i
         short8_t v;
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = f2bf(feat[lvl * 8 + i]);
-        *(short8_t*)(dst + lvl * 32) = v;
+        __builtin_nontemporal_store(v, (short8_t*)(dst + lvl * 32));      // streamed, as in store_features<true>
     }
 }
 

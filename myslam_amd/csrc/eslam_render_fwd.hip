@@ -27,6 +27,12 @@ struct LossIn {
 
 // LOWP: the mixed-precision tile of eslam_decode_tile.h (fp16 plane copies, bf16 MFMA decoders); channels-last only.
 template <bool CL, bool SAVE, bool LOSS, bool LOWP>
+#ifndef FWD_FEAT_NT
+#define FWD_FEAT_NT 1            // A/B switches (make variant VFLAGS=-DFWD_FEAT_NT=0 / -DFWD_CHAIN=0)
+#endif
+#ifndef FWD_CHAIN
+#define FWD_CHAIN 1
+#endif
 #ifndef FWD_WAVES
 #define FWD_WAVES 2            // waves per SIMD the gather kernels are compiled for: with one plane of loads in flight
                                // ahead of the FMAs the forward kernel needs 195 VGPRs; 2 waves/SIMD measured fastest
@@ -82,19 +88,47 @@ __global__ __launch_bounds__(256, FWD_WAVES) void render_fwd_kernel(const PlaneS
         const int nblk = (nvalid + 15) >> 4;
 
         float4_t out[2];
+        // gather role: normalised coordinates of point 16b + gp of the chunk
+        auto block_point = [&](int b, float& px, float& py, float& pz) {
+            const float zb = zrow[min(c0 + 16 * b + gp, S - 1)];
+            px = norm_coord(ox + dx * zb, bnd.lo[0], bnd.hi[0]);
+            py = norm_coord(oy + dy * zb, bnd.lo[1], bnd.hi[1]);
+            pz = norm_coord(oz + dz * zb, bnd.lo[2], bnd.hi[2]);
+        };
+        constexpr bool CHAIN = CL && !LOWP && FWD_CHAIN != 0;    // float32 channels-last planes: texel requests run one block ahead
+        PlaneTaps carry;
+        float cx = 0.f, cy = 0.f, cz = 0.f;
+        if (CHAIN) {
+            block_point(0, cx, cy, cz);
+            issue_plane0(planes, 0, cx, cy, cz, gq, opaque_zero(c0), carry);
+        }
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
             out[d] = LOWP ? *(const float4_t*)(lp_biases(wlds, d) + 32) : *(const float4_t*)(wlds + d * DEC_LDS + DEC_B3);
 #pragma unroll 1
             for (int b = 0; b < nblk; ++b) {
                 const int oz0 = opaque_zero(b);
-                // gather role: normalised coordinates of point 16b + gp
                 const int sb = c0 + 16 * b + gp;
-                const float zb = zrow[min(sb, S - 1)];
-                const float px = norm_coord(ox + dx * zb, bnd.lo[0], bnd.hi[0]);
-                const float py = norm_coord(oy + dy * zb, bnd.lo[1], bnd.hi[1]);
-                const float pz = norm_coord(oz + dz * zb, bnd.lo[2], bnd.hi[2]);
                 float feat[16];
+                if (CHAIN) {
+                    const bool last = b + 1 == nblk;
+                    float nx, ny, nz;
+                    block_point(last ? 0 : b + 1, nx, ny, nz);
+                    gather_features_chain(planes, d, cx, cy, cz, gq, feat, oz0, carry, last ? 1 : d, nx, ny, nz);
+                    cx = nx; cy = ny; cz = nz;
+                    if (SAVE) {
+                        if (sb < S) store_features<FWD_FEAT_NT != 0>(feat_out, (int64_t)ray * S + sb, d, gq, feat);
+                    }
+                    to_mfma_role<CL, 16>(feat, lane);
+                    DecFrag f;
+                    load_dec_frag(f, wlds + d * DEC_LDS + oz0, r, q);
+                    float4_t h1, h2;
+                    mlp_hidden(f, feat, h1, h2);
+                    mlp_out_accum(f, h2, b, r, out[d]);
+                    continue;
+                }
+                float px, py, pz;
+                block_point(b, px, py, pz);
                 if (LOWP) {
                     gather_features_half(planes, d, px, py, pz, gq, feat, oz0);
                     if (SAVE) {
@@ -110,7 +144,7 @@ __global__ __launch_bounds__(256, FWD_WAVES) void render_fwd_kernel(const PlaneS
                 }
                 gather_features<CL>(planes, d, px, py, pz, gq, feat, oz0);
                 if (SAVE) {
-                    if (sb < S) store_features(feat_out, (int64_t)ray * S + sb, d, gq, feat);
+                    if (sb < S) store_features<FWD_FEAT_NT != 0>(feat_out, (int64_t)ray * S + sb, d, gq, feat);
                 }
                 to_mfma_role<CL, 16>(feat, lane);
                 // operand fragments are re-read from LDS per block (9 ds_read_b128) instead of being kept live across
@@ -225,7 +259,7 @@ __global__ __launch_bounds__(256, FWD_WAVES) void decode_fwd_kernel(const PlaneS
                 float feat[16];
                 gather_features<CL>(planes, d, px, py, pz, gq, feat, oz0);
                 if (SAVE) {
-                    if (pb < N) store_features(feat_out, pb, d, gq, feat);
+                    if (pb < N) store_features<FWD_FEAT_NT != 0>(feat_out, pb, d, gq, feat);
                 }
                 to_mfma_role<CL, 16>(feat, lane);
                 DecFrag f;

@@ -21,11 +21,14 @@ _SEPARATE_LOSS = os.environ.get("ESLAM_SEPARATE_LOSS", "0") == "1"
 
 class Workload:
     def __init__(self, scene_name, R, n_strat, n_imp, device, zero_frac=0.0, seed=0, channels_last=True,
-                 rays_grad=False, planes="normal", model_seed=0, shard=None):
+                 rays_grad=False, planes="normal", model_seed=0, shard=None, state="initial"):
         """seed: image / pixel choice of this rank's rays; model_seed: planes and decoders (same on every rank of a
         data-parallel job, whose replicas must be identical).  shard = (rank, world): build the WHOLE batch (give every
         rank the same seed) and keep this rank's contiguous slice of its rays (parallel.shard_slice) - the ray-sharded
-        mapping iteration of SURVEY.md section 8(e); R_total is the batch's ray count."""
+        mapping iteration of SURVEY.md section 8(e); R_total is the batch's ray count.
+        state: "initial" = the reference's initial state (planes ~ 0.01, sdf ~ 0: the FIRST sample of a ray takes 99.9 % of
+        the compositing weight); "trained" = planes x 60 and the SDF head's bias + 0.55, which spreads the weights over ~20
+        samples per ray - the state parity tests need to see the colour features of later samples at all."""
         dev = torch.device(device)
         self.device = dev
         sc = scn.make_scene(scene_name)
@@ -41,6 +44,14 @@ class Workload:
         torch.manual_seed(model_seed)
         self.decoders = Decoders(learnable_beta=sc.learnable_beta).to(dev)
         self.decoders.bound = sc.bound
+        if state == "trained":
+            with torch.no_grad():
+                for grp in self.planes:
+                    for p in grp:
+                        p.mul_(60.0)
+                self.decoders.output_linear.bias += 0.55
+        elif state != "initial":
+            raise ValueError(state)
         cfg = sc.cfg(perturb=True)
         cfg["rendering"]["n_stratified"] = n_strat
         cfg["rendering"]["n_importance"] = n_imp

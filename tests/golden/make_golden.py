@@ -144,7 +144,11 @@ def plane_probes(grads, stream):
 
 
 def render_case(ref, name, scene_name, R, n_strat, n_imp, zero_frac, perturb=True, probe=None,
-                rays_grad=True, rng_base=50_000, img_stream=10, loss_kind="mapping"):
+                rays_grad=True, rng_base=50_000, img_stream=10, loss_kind="mapping", plane_scale=1.0, sdf_bias=0.0):
+    """plane_scale / sdf_bias: a "trained-like" state.  With the reference's initial state (planes ~ 0.01, sdf ~ 0) the
+    first sample of a ray takes 99 % of the compositing weight, so depth, colour and their gradients say nothing about the
+    colour features of later samples.  Planes scaled to O(1) features and the SDF head shifted positive spread the weights
+    over ~10 samples with a different profile per ray (and give the importance sampler a non-trivial pdf)."""
     cfg, ns, sc = ref_setup(ref, scene_name)
     cfg["rendering"]["perturb"] = perturb
     renderer = ref.Renderer(cfg, ns)
@@ -153,7 +157,10 @@ def render_case(ref, name, scene_name, R, n_strat, n_imp, zero_frac, perturb=Tru
     trunc = cfg["model"]["truncation"]
 
     planes = scn.synth_planes(sc, channels_last=False)
-    all_planes = tuple([torch.nn.Parameter(p) for p in grp] for grp in planes)
+    all_planes = tuple([torch.nn.Parameter(p * plane_scale) for p in grp] for grp in planes)
+    if sdf_bias:
+        with torch.no_grad():
+            decoders.output_linear.bias += sdf_bias
 
     depth_img = torch.from_numpy(synth.depth_image(sc.H, sc.W, img_stream, zero_frac))[None]
     color_img = torch.from_numpy(synth.color_image(sc.H, sc.W, img_stream + 2))[None]
@@ -197,7 +204,7 @@ def render_case(ref, name, scene_name, R, n_strat, n_imp, zero_frac, perturb=Tru
         scene=scene_name, R=np.int64(R), R_eff=np.int64(Re), n_stratified=np.int64(n_strat),
         n_importance=np.int64(n_imp), zero_frac=np.float64(zero_frac), perturb=np.bool_(perturb),
         truncation=np.float64(trunc), img_stream=np.int64(img_stream), rng_base=np.int64(rng_base),
-        loss_kind=loss_kind, rand_calls=rng.calls_array(),
+        loss_kind=loss_kind, rand_calls=rng.calls_array(), plane_scale=np.float64(plane_scale),
         beta_is_param=np.bool_(isinstance(decoders.beta, torch.nn.Parameter)),
         beta=np.float32(float(decoders.beta)),
         rays_o=ro.detach().numpy(), rays_d=rd.detach().numpy(), gt_depth=gt_depth_f.numpy(),
@@ -466,9 +473,15 @@ def main():
     # tracking loss (median mask), pose gradients only matter there
     if want("room0_200x40_tracking"):
         render_case(ref, "room0_200x40_tracking", "room0", 200, 32, 8, 0.0, loss_kind="tracking")
+    # a trained-like state (compositing weights spread over many samples), 15 % of the rays without depth
+    if want("room0_200x40_trained_zero15"):
+        render_case(ref, "room0_200x40_trained_zero15", "room0", 200, 32, 8, 0.15, plane_scale=60.0, sdf_bias=0.55)
     # BASELINE.json configs[1]: 4096 x 64 (56+8) - 64-ray probe + checksums
     if want("room0_4096x64"):
         render_case(ref, "room0_4096x64", "room0", 4096, 56, 8, 0.0, probe=64)
+    # the bench shape in the trained-like state, 10 % of the rays without depth
+    if want("room0_4096x64_trained_zero10"):
+        render_case(ref, "room0_4096x64_trained_zero10", "room0", 4096, 56, 8, 0.10, probe=64, plane_scale=60.0, sdf_bias=0.55)
     # BASELINE.json configs[3]: scene0000, 8192 x 96 (88+8), 10 % zero-depth
     if want("scene0000_8192x96_zero10"):
         render_case(ref, "scene0000_8192x96_zero10", "scene0000", 8192, 88, 8, 0.10, probe=64)

@@ -114,7 +114,7 @@ def test_render_fwd_bwd_matches_reference_fixture(case):
     check_against_fixture(fx, run_hip(fx))
 
 
-@pytest.mark.parametrize("case", ["room0_200x32", "room0_200x40_zero15"])
+@pytest.mark.parametrize("case", ["room0_200x32", "room0_200x40_zero15", "room0_200x40_trained_zero15"])
 def test_render_nchw_planes(case):
     """Planes exactly as the reference allocates them (NCHW-contiguous) go through the strided kernels."""
     fx = hp.load(case)
@@ -124,31 +124,56 @@ def test_render_nchw_planes(case):
         assert p.grad.stride() == p.stride()
 
 
-@pytest.mark.parametrize("case", ["room0_200x32", "room0_200x40_zero15", "room0_200x40_tracking"])
+@pytest.mark.parametrize("case", ["room0_200x32", "room0_200x40_zero15", "room0_200x40_tracking", "room0_200x40_trained_zero15"])
 def test_fused_loss_matches(case):
     fx = hp.load(case)
     check_against_fixture(fx, run_hip(fx, fused_loss=True))
 
 
-@pytest.mark.parametrize("case", ["room0_200x32", "room0_200x40_zero15"])
+@pytest.mark.parametrize("case", ["room0_200x32", "room0_200x40_zero15", "room0_200x40_trained_zero15"])
 def test_full_gradients_vs_oracle(case):
-    """Every element of every gradient (not only fixture probes) against autograd over the float64 oracle."""
+    """Every element of every gradient (not only fixture probes) against autograd over the float64 oracle.  In the
+    trained-like state float32 round-off is amplified by the loss's 200x-weighted terms (the float32 ORACLE is 5e-4 from the
+    float64 one on a plane gradient there), so the comparator is the float32 oracle - the reference's arithmetic - and the
+    float64 one bounds it, as in test_random_configurations_against_oracle."""
     from tests.test_oracle_golden import run_oracle
     fx = hp.load(case)
     r = run_hip(fx)
     o = run_oracle(fx, torch.float64)
+    o32 = run_oracle(fx, torch.float32) if "trained" in case else None
     assert hp.rel_err(r["sdf"].detach().cpu().numpy(), o["sdf"].detach().numpy()) <= RTOL
     assert hp.rel_err(r["depth"].detach().cpu().numpy(), o["depth"].detach().numpy()) <= RTOL
     assert hp.rel_err(r["color"].detach().cpu().numpy(), o["color"].detach().numpy()) <= RTOL
-    for a, b in zip(hp.flat_planes(r["planes"]), hp.flat_planes(o["planes"])):
-        assert hp.rel_err(a.grad.cpu().numpy(), b.grad.numpy()) <= RTOL
-    assert hp.rel_err(r["ro"].grad.cpu().numpy(), o["ro"].grad.numpy()) <= RTOL
-    assert hp.rel_err(r["rd"].grad.cpu().numpy(), o["rd"].grad.numpy()) <= RTOL
+
+    def close(a, b64, b32):
+        if b32 is None:
+            return hp.rel_err(a, b64.numpy()) <= RTOL
+        return (hp.rel_err(a, b32.double().numpy()) <= RTOL and
+                hp.rel_err(a, b64.numpy()) <= max(RTOL, 1.5 * hp.rel_err(b32.double().numpy(), b64.numpy())))
+
+    if o32 is None:
+        for k, (a, b) in enumerate(zip(hp.flat_planes(r["planes"]), hp.flat_planes(o["planes"]))):
+            assert close(a.grad.cpu().numpy(), b.grad, None), k
+    else:
+        from oracle import eslam_oracle as orc
+        from myslam_amd import scene as scn
+        sc = scn.make_scene(str(fx["scene"]))
+        pts = (o["ro"].detach()[:, None, :] + o["rd"].detach()[:, None, :] * o["z"].detach()[..., None]).reshape(-1, 3)
+        pn = orc.normalize_points(pts, sc.bound.double())
+        amb = hp.ambiguous_samples(pn, tuple([p.detach() for p in grp] for grp in o["planes"]),
+                                   {k: v.detach() for k, v in o["params"].items()})
+        ok, msg = hp.plane_grads_close([p.grad.cpu().numpy() for p in hp.flat_planes(r["planes"])],
+                                       [p.grad.numpy() for p in hp.flat_planes(o32["planes"])],
+                                       [p.grad.numpy() for p in hp.flat_planes(o["planes"])], pn, amb, sc.plane_shapes, RTOL)
+        assert ok, (msg, int(amb.sum()))
+    assert close(r["ro"].grad.cpu().numpy(), o["ro"].grad, o32["ro"].grad if o32 else None)
+    assert close(r["rd"].grad.cpu().numpy(), o["rd"].grad, o32["rd"].grad if o32 else None)
     if bool(fx["beta_is_param"]):
-        assert hp.rel_err(r["dec"].beta.grad.cpu().numpy(), o["beta"].grad.numpy()) <= RTOL
+        assert close(r["dec"].beta.grad.cpu().numpy(), o["beta"].grad, o32["beta"].grad if o32 else None)
 
 
-@pytest.mark.parametrize("case", ["room0_200x32", "room0_200x40_zero15", "room0_4096x64", "scene0000_8192x96_zero10"])
+@pytest.mark.parametrize("case", ["room0_200x32", "room0_200x40_zero15", "room0_4096x64", "scene0000_8192x96_zero10",
+                                  "room0_200x40_trained_zero15", "room0_4096x64_trained_zero10"])
 def test_loss_sums_in_the_forward_epilogue(case):
     """eslam_render_fwd_loss: the forward kernel forms the loss sums itself; value, accumulators and every gradient must
     match the reference fixture and the separate eslam_loss_value launch."""
@@ -574,14 +599,15 @@ def test_matched_loss_over_adam_iterations():
 
 @pytest.mark.parametrize("R,ns,ni,zero_frac", [(1, 24, 8, 0.0), (3, 5, 3, 0.0), (7, 32, 8, 1.0), (130, 100, 28, 0.3),
                                                (33, 16, 0, 0.0), (65, 200, 56, 0.2)])
-def test_edge_shapes_against_oracle(R, ns, ni, zero_frac):
+@pytest.mark.parametrize("state", ["initial", "trained"])
+def test_edge_shapes_against_oracle(R, ns, ni, zero_frac, state):
     """Ragged sizes: a single ray, R not a multiple of the 4 rays per workgroup, S not a multiple of 16, S > 64 (two and
     four 64-sample chunks per ray, up to the 256 maximum), every ray without depth, no surface samples at all."""
     from oracle import eslam_oracle as orc
     from myslam_amd import harness, synth
     dev = _dev()
     wl = harness.make_workload("room0", max(R, 8) * 4, ns, ni, device=dev, zero_frac=zero_frac, planes="synth",
-                               rays_grad=True)
+                               rays_grad=True, state=state)
     sl = slice(0, R)
     ro, rd = wl.rays_o[sl].detach().requires_grad_(True), wl.rays_d[sl].detach().requires_grad_(True)
     gd, gc = wl.gt_depth[sl], wl.gt_color[sl]
@@ -594,19 +620,26 @@ def test_edge_shapes_against_oracle(R, ns, ni, zero_frac):
     cot = torch.from_numpy(synth.hash_uniform((R, S), 10)).to(dev) - 0.5
     ((depth * 0.7).sum() + (color * 0.3).sum() + (sdf * cot).sum()).backward()
     # float64 oracle on the CPU with the kernel's own z_vals (the samplers are checked against the fixtures)
-    cplanes = tuple([p.detach().cpu().double().contiguous().requires_grad_(True) for p in grp] for grp in wl.planes)
-    cparams = {k: v.detach().cpu().double().requires_grad_(True) for k, v in wl.decoders.state_dict().items() if k != "beta"}
-    cbeta = wl.decoders.beta.detach().cpu().double().requires_grad_(True)
-    cro, crd = ro.detach().cpu().double().requires_grad_(True), rd.detach().cpu().double().requires_grad_(True)
-    has = (gd > 0).cpu()
-    zo = orc.sample_z(cro.detach(), crd.detach(), gd.cpu().double(), cplanes, cparams, cbeta.detach(), wl.scene.bound.double(),
-                      wl.truncation, ns, ni, *(t.cpu().double() for t in rand))
-    assert torch.equal(z.cpu()[has], zo.float()[has]) or hp.rel_err(z.cpu()[has].numpy(), zo[has].numpy()) <= 1e-6
-    if (~has).any():
-        assert hp.rel_err(z.cpu()[~has].numpy(), zo[~has].numpy()) <= RTOL
-    od, oc, os_, _ = orc.render_batch_ray(cplanes, cparams, cbeta, wl.scene.bound, crd, cro, wl.truncation, gd.cpu().double(),
-                                          ns, ni, z_vals=z.detach().cpu().double())
-    ((od * 0.7).sum() + (oc * 0.3).sum() + (os_ * cot.cpu().double()).sum()).backward()
+    def oracle_run(dtype, check_z=False):
+        cv = lambda t: t.detach().cpu().to(dtype)
+        cplanes = tuple([cv(p).contiguous().requires_grad_(True) for p in grp] for grp in wl.planes)
+        cparams = {k: cv(v).requires_grad_(True) for k, v in wl.decoders.state_dict().items() if k != "beta"}
+        cbeta = cv(wl.decoders.beta).requires_grad_(True)
+        cro, crd = cv(ro).requires_grad_(True), cv(rd).requires_grad_(True)
+        if check_z:
+            has = (gd > 0).cpu()
+            zo = orc.sample_z(cro.detach(), crd.detach(), cv(gd), cplanes, cparams, cbeta.detach(), wl.scene.bound.to(dtype),
+                              wl.truncation, ns, ni, *(cv(t) for t in rand))
+            assert torch.equal(z.cpu()[has], zo.float()[has]) or hp.rel_err(z.cpu()[has].numpy(), zo[has].numpy()) <= 1e-6
+            if (~has).any():
+                assert hp.rel_err(z.cpu()[~has].numpy(), zo[~has].numpy()) <= RTOL
+        od, oc, os_, _ = orc.render_batch_ray(cplanes, cparams, cbeta, wl.scene.bound, crd, cro, wl.truncation, cv(gd),
+                                              ns, ni, z_vals=cv(z))
+        ((od * 0.7).sum() + (oc * 0.3).sum() + (os_ * cv(cot)).sum()).backward()
+        return dict(out=(od, oc, os_), planes=cplanes, params=cparams, beta=cbeta, ro=cro, rd=crd)
+
+    o = oracle_run(torch.float64, check_z=True)
+    od, oc, os_ = o["out"]
     assert hp.rel_err(depth.detach().cpu().numpy(), od.detach().numpy()) <= RTOL
     assert hp.rel_err(color.detach().cpu().numpy(), oc.detach().numpy()) <= RTOL
     assert hp.rel_err(sdf.detach().cpu().numpy(), os_.detach().numpy()) <= RTOL
@@ -614,14 +647,24 @@ def test_edge_shapes_against_oracle(R, ns, ni, zero_frac):
     # a few of the ~10^5 coordinates on different sides of one (|ix - round(ix)| < float32 eps happens ~6e-5 of the
     # time).  Those rays differ by a finite amount that is not an error of either side: require 97 % of the rays inside
     # the tolerance and the rest bounded.  (Against the float32 fixtures of the reference the full 1e-4 holds.)
-    for a, b in ((ro.grad.cpu().numpy(), cro.grad.numpy()), (rd.grad.cpu().numpy(), crd.grad.numpy())):
+    for a, b in ((ro.grad.cpu().numpy(), o["ro"].grad.numpy()), (rd.grad.cpu().numpy(), o["rd"].grad.numpy())):
         per_ray = np.abs(a - b).max(1) / (np.abs(b).max() + 1e-30)
         assert np.quantile(per_ray, 0.97) <= RTOL and per_ray.max() <= 0.05, (np.quantile(per_ray, 0.97), per_ray.max())
-    for a, b in zip(wl.plane_list, hp.flat_planes(cplanes)):
-        assert hp.rel_err(a.grad.cpu().numpy(), b.grad.numpy()) <= RTOL
+    # plane gradients: float32 oracle as comparator, float64 as the conditioning bound, texels of ReLU-ambiguous samples
+    # set aside (helpers.ambiguous_samples; they only occur in the trained-like state)
+    o32 = oracle_run(torch.float32)
+    pts = (o["ro"].detach()[:, None, :] + o["rd"].detach()[:, None, :] * z.detach().cpu().double()[..., None]).reshape(-1, 3)
+    pn = orc.normalize_points(pts, wl.scene.bound.double())
+    amb = hp.ambiguous_samples(pn, tuple([p.detach() for p in grp] for grp in o["planes"]), {k: v.detach() for k, v in o["params"].items()})
+    ok, msg = hp.plane_grads_close([p.grad.cpu().numpy() for p in wl.plane_list], [p.grad.numpy() for p in hp.flat_planes(o32["planes"])],
+                                   [p.grad.numpy() for p in hp.flat_planes(o["planes"])], pn, amb, wl.scene.plane_shapes, RTOL)
+    assert ok, (msg, int(amb.sum()))
+    slack = 4.0 * float(amb.sum()) / max(1, amb.numel())
     for k, t in wl.decoders.named_parameters():
-        ref = cbeta.grad if k == "beta" else cparams[k].grad
-        assert hp.rel_err(t.grad.cpu().numpy(), ref.numpy()) <= RTOL, k
+        ref = o["beta"].grad if k == "beta" else o["params"][k].grad
+        ref32 = o32["beta"].grad if k == "beta" else o32["params"][k].grad
+        assert hp.rel_err(t.grad.cpu().numpy(), ref32.double().numpy()) <= RTOL + slack, k
+        assert hp.rel_err(t.grad.cpu().numpy(), ref.numpy()) <= max(RTOL, 1.5 * hp.rel_err(ref32.double().numpy(), ref.numpy())) + slack, k
 
 
 @pytest.mark.parametrize("seed", range(8))
@@ -641,7 +684,9 @@ def test_random_configurations_against_oracle(seed):
     n = int(rng.integers(1, 160))
     zero_frac = float(rng.choice([0.0, 0.1, 0.5]))
     cl = bool(rng.integers(2))
-    wl = harness.make_workload(scene_name, 16, ns, ni, device=dev, planes="synth", channels_last=cl)
+    # odd seeds: the trained-like state (harness.Workload), where every sample of a ray carries compositing weight
+    wl = harness.make_workload(scene_name, 16, ns, ni, device=dev, planes="synth", channels_last=cl,
+                               state="trained" if seed % 2 else "initial")
     sc = wl.scene
     c2ws = torch.eye(4).repeat(b, 1, 1)
     for i in range(b):
@@ -683,14 +728,24 @@ def test_random_configurations_against_oracle(seed):
     for a, r in zip((depth, color, sdf), o64):
         assert hp.rel_err(a.detach().cpu().numpy(), r) <= RTOL, desc
     mine = [p.grad.cpu().double().numpy() for p in wl.plane_list] + [t.grad.cpu().double().numpy() for _, t in wl.decoders.named_parameters()]
-    for k, (a, r32, r64_) in enumerate(zip(mine, g32, g64)):
-        assert hp.rel_err(a, r32) <= RTOL, (desc, k)
-        assert hp.rel_err(a, r64_) <= max(RTOL, 1.5 * hp.rel_err(r32, r64_)), (desc, k)
+    pts = (ro.detach().cpu().double()[:, None, :] + rd.detach().cpu().double()[:, None, :] * z.cpu().double()[..., None])
+    pn = orc.normalize_points(pts.reshape(-1, 3), sc.bound.double())
+    cv64 = lambda t: t.detach().cpu().double()
+    amb = hp.ambiguous_samples(pn, tuple([cv64(p).contiguous() for p in grp] for grp in wl.planes),
+                               {k: cv64(v) for k, v in wl.decoders.state_dict().items() if k != "beta"})
+    assert amb.float().mean() <= 5e-3, (desc, int(amb.sum()))
+    ok, msg = hp.plane_grads_close(mine[:12], g32[:12], g64[:12], pn, amb, sc.plane_shapes, RTOL)
+    assert ok, (desc, msg, int(amb.sum()))
+    for k, (a, r32, r64_) in enumerate(zip(mine[12:], g32[12:], g64[12:])):
+        # a decoder gradient sums over all samples: an ambiguous sample moves it by its own share
+        slack = 4.0 * float(amb.sum()) / max(1, amb.numel())
+        assert hp.rel_err(a, r32) <= RTOL + slack, (desc, k)
+        assert hp.rel_err(a, r64_) <= max(RTOL, 1.5 * hp.rel_err(r32, r64_)) + slack, (desc, k)
     # Ray gradients: the position gradient of a bilinear lookup jumps at texel boundaries, so a ray may differ by a finite
     # amount when float32 and float64 put one of its samples on different sides of one.  Every ray outside the tolerance
     # must be explained that way: one of its samples lies within 2e-4 texels of a boundary of one of the 12 planes.
-    pts = (ro.detach().cpu().double()[:, None, :] + rd.detach().cpu().double()[:, None, :] * z.cpu().double()[..., None])
-    pn = orc.normalize_points(pts.reshape(-1, 3), sc.bound.double()).reshape(R, S, 3)
+    pn = pn.reshape(R, S, 3)
+    amb_ray = amb.reshape(R, S).any(1).numpy()
     near = torch.full((R,), 1e9, dtype=torch.float64)
     for g, (ax, ay) in enumerate([(0, 1), (0, 2), (1, 2)] * 2):
         for lvl in range(2):
@@ -704,7 +759,7 @@ def test_random_configurations_against_oracle(seed):
         per_ray = np.abs(a - r).max(1) / (np.abs(r).max() + 1e-30)
         bad = per_ray > RTOL
         assert bad.mean() <= 0.03, (desc, bad.mean())
-        assert np.all(near.numpy()[bad] < 2e-4), (desc, per_ray[bad], near.numpy()[bad])
+        assert np.all((near.numpy()[bad] < 2e-4) | amb_ray[bad]), (desc, per_ray[bad], near.numpy()[bad])
 
 
 def test_mixed_precision_tolerance_study():
@@ -859,3 +914,54 @@ def test_multi_camera_batch_against_oracle():
     for k, (a, r32, r64) in enumerate(zip(mine, g32, g64)):
         assert hp.rel_err(a, r32) <= RTOL, k
         assert hp.rel_err(a, r64) <= max(RTOL, 1.5 * hp.rel_err(r32, r64)), k
+
+
+@pytest.mark.parametrize("scene,R,ns,ni", [("toy", 64, 32, 8), ("room0", 37, 120, 8), ("room0", 5, 9, 2), ("room0", 130, 56, 8)])
+@pytest.mark.parametrize("channels_last", [True, False])
+def test_saved_features_and_raw_colour_of_every_sample(scene, R, ns, ni, channels_last):
+    """What the forward pass SAVES for the backward pass, element by element against the float64 oracle: the 128 features
+    and the raw colour of EVERY sample, in the trained-like state (O(1) features).  The composited outputs cannot see
+    them in the reference's initial state - there the first sample of a ray takes 99.9 % of the weight - which is how a
+    forward kernel that gathered the colour features of samples 16.. at the wrong positions (an inline-asm statement
+    without its SCC clobber next to a select) once passed every other test of this file."""
+    import ctypes
+    from oracle import eslam_oracle as orc
+    from myslam_amd import _hip, harness, ops
+    dev = _dev()
+    wl = harness.make_workload(scene, max(R, 8) * 2, ns, ni, device=dev, planes="synth", channels_last=channels_last,
+                               state="trained")
+    R = min(R, wl.R)                      # (rays that leave the bound before their depth are dropped by the workload)
+    ro, rd, gd = wl.rays_o[:R].detach().contiguous(), wl.rays_d[:R].detach().contiguous(), wl.gt_depth[:R].contiguous()
+    with torch.no_grad():
+        z = wl.renderer.render_batch_ray(wl.planes, wl.decoders, rd, ro, dev, wl.truncation, gt_depth=gd)[3].contiguous()
+    S = ns + ni
+    feat, raw = torch.full((R * S, 128), -7.0, device=dev), torch.full((R * S, 3), -7.0, device=dev)
+    depth, rgb, sdf = torch.empty(R, device=dev), torch.empty(R, 3, device=dev), torch.empty(R, S, device=dev)
+    arr, _keep = _hip.make_planes(tuple([p.detach() for p in grp] for grp in wl.planes))
+    dec, _keep2 = _hip.make_decoders([p.detach() for p in ops.decoder_params(wl.decoders)],
+                                     ops.beta_tensor(wl.decoders.beta, dev).detach())
+    with _hip.on_device(dev):
+        _hip.check(_hip.lib().eslam_render_fwd(arr, ctypes.byref(dec), _hip.make_bound(ops.bound_to_host(wl.scene.bound)),
+                                               _hip.ptr(ro), _hip.ptr(rd), _hip.ptr(z), R, S, _hip.ptr(depth), _hip.ptr(rgb),
+                                               _hip.ptr(sdf), _hip.ptr(raw), _hip.ptr(feat), None, None,
+                                               _hip.stream_handle(dev)), "eslam_render_fwd")
+    torch.cuda.synchronize()
+    cv = lambda t: t.detach().cpu().double()
+    planes = tuple([cv(p).contiguous() for p in grp] for grp in wl.planes)
+    params = {k: cv(v) for k, v in wl.decoders.state_dict().items() if k != "beta"}
+    pts = (cv(ro)[:, None, :] + cv(rd)[:, None, :] * cv(z)[..., None]).reshape(-1, 3)
+    pn = orc.normalize_points(pts, wl.scene.bound.double())
+    ref_feat = torch.cat([orc.plane_features(pn, *planes[:3]), orc.plane_features(pn, *planes[3:])], -1)
+    ref_raw = orc.raw_rgb(pn, planes, params)
+    ref_sdf = orc.raw_sdf(pn, planes, params).reshape(R, S)
+    assert float(ref_feat.abs().mean()) > 0.05                          # O(1) features, not the 1e-2 of the initial state
+    # per 16-sample block of the rays (the unit the kernel decodes), so that a failure names the block
+    f, r = feat.cpu().double().reshape(R, S, 128), ref_feat.reshape(R, S, 128)
+    for b in range((S + 15) // 16):
+        sl = slice(16 * b, min(S, 16 * b + 16))
+        for d in range(2):
+            err = float((f[:, sl, 64 * d:64 * d + 64] - r[:, sl, 64 * d:64 * d + 64]).abs().max())
+            assert err <= RTOL * float(r.abs().max()), f"features of decoder {d}, samples {sl}: {err}"
+    for name, a, b in (("raw colour", raw, ref_raw), ("sdf", sdf, ref_sdf)):
+        ok, info = hp.elementwise_close(a.cpu().double().numpy(), b.numpy(), rtol=RTOL, floor=1e-5)
+        assert ok, (name, info)
