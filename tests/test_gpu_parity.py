@@ -762,14 +762,26 @@ def test_random_configurations_against_oracle(seed):
         assert np.all((near.numpy()[bad] < 2e-4) | amb_ray[bad]), (desc, per_ray[bad], near.numpy()[bad])
 
 
-def test_mixed_precision_tolerance_study():
+MIXED_CASES = {
+    # case: (forward bounds: sdf, rgb, relative depth), (training bounds: loss, plane gradients, 1 - cosine, decoder gradients)
+    "freiburg1_desk_5000x56_zero10": ((5e-3, 5e-3, 2e-2), (2e-4, 1e-2, 1e-4, 1.2e-2)),
+    # the trained-like state: O(1) features, compositing weights spread over ~20 samples of a ray
+    # measured: sdf 8.7e-4 / 1.4e-3 (vs reference float32 / float64 oracle), rgb 4e-5 / 7e-5, depth 1.4e-3 / 1.9e-3; training
+    # step: loss 8.7e-6, plane gradients 6.8e-3 (cosine 0.999963), decoder gradients 4.9e-3
+    "room0_4096x64_trained_zero10": ((3e-3, 5e-4, 5e-3), (2e-4, 1.5e-2, 1e-4, 1.2e-2)),
+}
+
+
+@pytest.mark.parametrize("case", list(MIXED_CASES))
+def test_mixed_precision_tolerance_study(case):
     """BASELINE.json configs[4]: freiburg1_desk, 5000 rays x 56 samples, fp16 planes + bf16 MFMA decoders.  A tolerance
     STUDY against (a) the outputs of the REFERENCE itself (the float32 fixture) and (b) the float64 oracle on the same
     rays and z_vals: the bounds are what the formats allow (half has 11 significant bits, bf16 8), recorded in DESIGN.md -
     not the 1e-4 parity bar, which only the float32 path is held to."""
     from myslam_amd import lowp
     from tests.test_oracle_golden import run_oracle
-    fx = hp.load("freiburg1_desk_5000x56_zero10")
+    fx = hp.load(case)
+    b_sdf, b_rgb, b_dep = MIXED_CASES[case][0]
     dev = _dev()
     sc, planes, dec, renderer = build(fx, planes_grad=False, dec_grad=False)
     t_rand, t_uni, u = hp.rand_inputs(fx)
@@ -787,8 +799,8 @@ def test_mixed_precision_tolerance_study():
     e_sdf = float(np.abs(s16.cpu().numpy()[pr][has] - fx["sdf"][has]).max())
     e_rgb = float(np.abs(c16.cpu().numpy()[pr] - fx["color"]).max())
     e_dep = float((np.abs(d16.cpu().numpy()[pr] - fx["depth"]) / np.maximum(np.abs(fx["depth"]), 1e-3)).max())
-    print(f"mixed precision vs the reference's float32 outputs: max|sdf| {e_sdf:.2e}  max|rgb| {e_rgb:.2e}  max rel depth {e_dep:.2e}")
-    assert e_sdf < 5e-3 and e_rgb < 5e-3 and e_dep < 2e-2
+    print(f"{case}: mixed precision vs the reference's float32 outputs: max|sdf| {e_sdf:.2e}  max|rgb| {e_rgb:.2e}  max rel depth {e_dep:.2e}")
+    assert e_sdf < b_sdf and e_rgb < b_rgb and e_dep < b_dep
     # (b) the float64 oracle, every ray (z_vals of depth-less rays differ at 1e-4 between the paths: compare rays with depth)
     o = run_oracle(fx, torch.float64)
     hd = fx["gt_depth"] > 0
@@ -796,11 +808,12 @@ def test_mixed_precision_tolerance_study():
     e_rgb = float(np.abs(c16.cpu().numpy()[hd] - o["color"].detach().numpy()[hd]).max())
     e_dep = float((np.abs(d16.cpu().numpy()[hd] - o["depth"].detach().numpy()[hd]) /
                    np.maximum(np.abs(o["depth"].detach().numpy()[hd]), 1e-3)).max())
-    print(f"mixed precision vs the float64 oracle ({int(hd.sum())} rays): max|sdf| {e_sdf:.2e}  max|rgb| {e_rgb:.2e}  max rel depth {e_dep:.2e}")
-    assert e_sdf < 5e-3 and e_rgb < 5e-3 and e_dep < 2e-2
+    print(f"{case}: mixed precision vs the float64 oracle ({int(hd.sum())} rays): max|sdf| {e_sdf:.2e}  max|rgb| {e_rgb:.2e}  max rel depth {e_dep:.2e}")
+    assert e_sdf < b_sdf and e_rgb < b_rgb and e_dep < b_dep
 
 
-def test_mixed_precision_training_step_gradient_study():
+@pytest.mark.parametrize("case", list(MIXED_CASES))
+def test_mixed_precision_training_step_gradient_study(case):
     """BASELINE.json configs[4] as a TRAINING configuration: forward and backward of a mapping iteration on the mixed-precision
     kernels (fp16 plane copies, bf16-MFMA decoders both ways, float32 accumulation and float32 plane gradients) against
     autograd over the float64 oracle on the freiburg1_desk fixture (5000 rays x 56 samples, 10 % depth-less).  A tolerance
@@ -808,7 +821,8 @@ def test_mixed_precision_training_step_gradient_study():
     margin, and are recorded in DESIGN.md."""
     from myslam_amd import lowp, losses, ops
     from tests.test_oracle_golden import run_oracle
-    fx = hp.load("freiburg1_desk_5000x56_zero10")
+    fx = hp.load(case)
+    b_loss, b_planes, b_cos, b_dec = MIXED_CASES[case][1]
     dev = _dev()
     sc, planes, dec, renderer = build(fx)
     t_rand, t_uni, u = hp.rand_inputs(fx)
@@ -847,13 +861,13 @@ def test_mixed_precision_training_step_gradient_study():
              if k != "beta" or bool(fx["beta_is_param"])}
     cos = [float((a.cpu().double().flatten() @ b.grad.flatten()) / (a.cpu().double().norm() * b.grad.norm() + 1e-300))
            for a, b in zip(pg, hp.flat_planes(o["planes"]))]
-    print(f"mixed-precision training step vs float64 oracle: loss rel {e_loss:.2e}; plane gradients max-normalised error "
+    print(f"{case}: mixed-precision training step vs float64 oracle: loss rel {e_loss:.2e}; plane gradients max-normalised error "
           f"{max(e_planes):.2e} (geometry {max(e_planes[:6]):.2e}, colour {max(e_planes[6:]):.2e}), cosine >= {min(cos):.6f}; "
           f"decoder gradients {max(e_dec.values()):.2e} ({max(e_dec, key=e_dec.get)})")
     # measured on MI355X: loss 2.5e-5, plane gradients 3.2e-3 (cosine 0.999997), decoder gradients 4.0e-3
-    assert e_loss < 2e-4
-    assert max(e_planes) < 1e-2 and min(cos) > 0.9999
-    assert max(e_dec.values()) < 1.2e-2
+    assert e_loss < b_loss
+    assert max(e_planes) < b_planes and 1.0 - min(cos) < b_cos
+    assert max(e_dec.values()) < b_dec
 
 
 def test_multi_camera_batch_against_oracle():
