@@ -396,63 +396,9 @@ __device__ __forceinline__ void gather8_half(const eslam_plane_t& P, float u, fl
         acc[i] += (float)t00[i] * w00 + (float)t01[i] * w01 + (float)t10[i] * w10 + (float)t11[i] * w11;
 }
 
-// The same one-plane-ahead, one-block-ahead request chain as gather_features_chain, on the half copies of the planes: one
-// 16-byte load per corner (a quad of lanes = one whole 64-byte texel).
-struct HalfTaps {
-    half8_t t00, t01, t10, t11;
-    float w00, w01, w10, w11;
-};
-
-__device__ __forceinline__ void issue_taps_half(const eslam_plane_t& P, float u, float v, int g, HalfTaps& t) {
-    const AxisCoord ax = axis_coord(u, P.w);
-    const AxisCoord ay = axis_coord(v, P.h);
-    const unsigned sy = (unsigned)P.stride_y, sx = (unsigned)P.stride_x;
-    const unsigned r0 = ay.i0 * sy, r1 = ay.i1 * sy, c0 = ax.i0 * sx, c1 = ax.i1 * sx, g8 = 8u * g;
-    const _Float16* __restrict__ data = (const _Float16*)P.data_f16;
-    t.t00 = *(const half8_t*)(data + r0 + c0 + g8);
-    t.t01 = *(const half8_t*)(data + r0 + c1 + g8);
-    t.t10 = *(const half8_t*)(data + r1 + c0 + g8);
-    t.t11 = *(const half8_t*)(data + r1 + c1 + g8);
-    t.w00 = (1.0f - ax.t) * (1.0f - ay.t);
-    t.w01 = ax.t * (1.0f - ay.t);
-    t.w10 = (1.0f - ax.t) * ay.t;
-    t.w11 = ax.t * ay.t;
-}
-
-__device__ __forceinline__ void accumulate_taps_half(const HalfTaps& t, float acc[8]) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-        acc[i] += (float)t.t00[i] * t.w00 + (float)t.t01[i] * t.w01 + (float)t.t10[i] * t.w10 + (float)t.t11[i] * t.w11;
-}
-
-__device__ __forceinline__ void issue_plane0_half(const PlaneSet& planes, int d, float x, float y, float z, int g, int opaque0,
-                                                  HalfTaps& t) {
-    issue_taps_half(planes.p[6 * d + opaque0], ORIENT_U(0, x, y, z), ORIENT_V(0, x, y, z), g, t);
-}
-
-// the 64 features of decoder d for the lane's gather-role point: feat[lvl*8 + i] = channel 8g + i of the level; `carry`:
-// plane 0 of this block on entry, plane 0 of block (dn, xn, yn, zn) on return (see gather_features_chain)
-__device__ __forceinline__ void gather_features_half_chain(const PlaneSet& planes, int d, float x, float y, float z, int g,
-                                                           float feat[16], int opaque0, HalfTaps& carry, int dn, float xn,
-                                                           float yn, float zn) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) feat[i] = 0.0f;
-    HalfTaps odd;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const int kn = k + 1;
-        if (kn < 6) {
-            issue_taps_half(planes.p[2 * (3 * d + (kn % 3)) + (kn / 3) + opaque0], ORIENT_U(kn % 3, x, y, z),
-                            ORIENT_V(kn % 3, x, y, z), g, (kn & 1) ? odd : carry);
-        } else {
-            issue_plane0_half(planes, dn, xn, yn, zn, g, opaque0, carry);
-        }
-        accumulate_taps_half((k & 1) ? odd : carry, feat + 8 * (k / 3));
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// without the chain (the samplers' decode of depth-less rays)
+// the 64 features of decoder d for the lane's gather-role point: feat[lvl*8 + i] = channel 8g + i of the level.
+// (The request chain of gather_features_chain was tried here too: 216 instead of 166 VGPRs, 2 waves per SIMD instead of 3,
+// forward 82 -> 90 us at 5000 x 56.  Dropped.)
 __device__ __forceinline__ void gather_features_half(const PlaneSet& planes, int d, float x, float y, float z, int g,
                                                      float feat[16], int opaque0) {
 #pragma unroll

@@ -33,9 +33,6 @@ template <bool CL, bool SAVE, bool LOSS, bool LOWP>
 #ifndef FWD_CHAIN
 #define FWD_CHAIN 1
 #endif
-#ifndef FWD_CHAIN_LP
-#define FWD_CHAIN_LP 0
-#endif
 #ifndef FWD_WAVES
 #define FWD_WAVES 2            // waves per SIMD the gather kernels are compiled for: with one plane of loads in flight
                                // ahead of the FMAs the forward kernel needs 195 VGPRs; 2 waves/SIMD measured fastest
@@ -99,14 +96,11 @@ __global__ __launch_bounds__(256, FWD_WAVES) void render_fwd_kernel(const PlaneS
             pz = norm_coord(oz + dz * zb, bnd.lo[2], bnd.hi[2]);
         };
         constexpr bool CHAIN = CL && !LOWP && FWD_CHAIN != 0;    // float32 channels-last planes: texel requests run one block ahead
-        constexpr bool CHAIN_LP = LOWP && FWD_CHAIN_LP != 0;     // the same on the half copies
         PlaneTaps carry;
-        HalfTaps carry_lp;
         float cx = 0.f, cy = 0.f, cz = 0.f;
-        if (CHAIN || CHAIN_LP) {
+        if (CHAIN) {
             block_point(0, cx, cy, cz);
-            if (CHAIN) issue_plane0(planes, 0, cx, cy, cz, gq, opaque_zero(c0), carry);
-            else issue_plane0_half(planes, 0, cx, cy, cz, gq, opaque_zero(c0), carry_lp);
+            issue_plane0(planes, 0, cx, cy, cz, gq, opaque_zero(c0), carry);
         }
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
@@ -131,23 +125,6 @@ __global__ __launch_bounds__(256, FWD_WAVES) void render_fwd_kernel(const PlaneS
                     float4_t h1, h2;
                     mlp_hidden(f, feat, h1, h2);
                     mlp_out_accum(f, h2, b, r, out[d]);
-                    continue;
-                }
-                if (CHAIN_LP) {
-                    const bool last = b + 1 == nblk;
-                    float nx, ny, nz;
-                    block_point(last ? 0 : b + 1, nx, ny, nz);
-                    gather_features_half_chain(planes, d, cx, cy, cz, gq, feat, oz0, carry_lp, last ? 1 : d, nx, ny, nz);
-                    cx = nx; cy = ny; cz = nz;
-                    if (SAVE) {
-                        if (sb < S) store_features_lp(feat_out, (int64_t)ray * S + sb, d, gq, feat);
-                    }
-                    to_mfma_role<true, 16>(feat, lane);
-                    DecFragLP fl;
-                    load_dec_frag_lp(fl, lp_weights(wlds, d) + oz0, lp_biases(wlds, d) + oz0, r, q);
-                    float4_t a1, a2;
-                    mlp_hidden_lp(fl, feat, a1, a2);
-                    mlp_out_accum_lp(fl, a2, b, r, out[d]);
                     continue;
                 }
                 float px, py, pz;
