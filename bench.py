@@ -104,6 +104,14 @@ def timed(fn, n, warm):
     return (time.perf_counter() - t0) / n * 1e3
 
 
+def timed_median(fn, n, warm, reps=5):
+    """Median of `reps` timings of n calls each: a host-bound (eager) loop shares the box's cores with other tenants, and a
+    single short sample of it was off by 2x from one run to the next."""
+    for _ in range(warm):
+        fn()
+    return sorted(timed(fn, n, 0) for _ in range(reps))[reps // 2]
+
+
 def cpu_baseline(wl, budget_s=25.0, max_iters=5):
     """Oracle on the host cores: forward + mapping loss + backward on the same rays / planes / decoders."""
     from oracle import eslam_oracle as orc
@@ -209,7 +217,7 @@ def side_measurements(cfg, wl, dev):
     from myslam_amd import harness, losses
     out = {}
     try:
-        out["eager_ms_per_step"] = round(timed(wl.step, 50, 10), 4)       # same step, every launch issued from Python
+        out["eager_ms_per_step"] = round(timed_median(wl.step, 100, 30), 4)  # same step, every launch issued from Python
 
         def reference_shaped():      # the reference loop's own call sequence: render_batch_ray, then the loss, then backward
             for p in wl.params():
@@ -217,12 +225,12 @@ def side_measurements(cfg, wl, dev):
             d, c, s, z = wl.renderer.render_batch_ray(wl.planes, wl.decoders, wl.rays_d, wl.rays_o, wl.device, wl.truncation,
                                                       gt_depth=wl.gt_depth)
             losses.mapping_loss(d, c, s, z, wl.gt_depth, wl.gt_color, wl.truncation).backward()
-        out["eager_separate_loss_ms_per_step"] = round(timed(reference_shaped, 50, 10), 4)
+        out["eager_separate_loss_ms_per_step"] = round(timed_median(reference_shaped, 100, 30), 4)
         wn = harness.make_workload(cfg["scene"], cfg["rays"], cfg["n_strat"], cfg["n_imp"], device=dev,
                                    zero_frac=cfg["zero_frac"], channels_last=False)
         gn = harness.GraphedStep(wn.step, wn.params())
         out["nchw_ms_per_step"] = round(timed(gn, 50, 10), 4)            # reference-layout planes, graph replay
-        out["nchw_eager_ms_per_step"] = round(timed(wn.step, 20, 5), 4)
+        out["nchw_eager_ms_per_step"] = round(timed_median(wn.step, 30, 10, reps=3), 4)
         del gn, wn
 
         def fwd():
@@ -288,13 +296,19 @@ def roofline(prof, n, ms_step):
              "note": "memory-side bytes of all kernels of a step (PMC) / ms_per_step; the algorithmic figure of SURVEY.md 8(d) "
                      "is kept as a labelled extra: the planes are L2 / Infinity-Cache resident, so it is NOT an HBM rate"}
     whole["frac"] = None if whole["achieved"] is None else whole["achieved"] / HBM_PEAK_GBS
-    dom = max(ks, key=lambda e: e["avg_kernel_ms"]) if ks else None
+    longest = max(ks, key=lambda e: e["avg_kernel_ms"]) if ks else None
+    # the contract's object describes the longest kernel; without PMC bytes for THIS build (the scatter's and the decoder
+    # backward's ceilings are priced on counter bytes) it describes the longest kernel whose rate the HIP events alone give
+    measurable = [e for e in ks if e.get("frac") is not None]
+    dom = max(measurable, key=lambda e: e["avg_kernel_ms"]) if measurable else longest
     top = None
     if dom is not None:
         top = {k: dom.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_kernel_ms",
                                        "algorithmic_bytes_per_launch")}
-        if top["achieved"] is None:          # no PMC numbers for this build: fall back to the rate the events alone give
-            top["note"] = "achieved needs the PMC bytes of this build; see kernels[] for the event-timed algorithmic rates"
+        if dom is not longest:
+            top["note"] = (f"the longest kernel is {longest['kernel']} ({longest['avg_kernel_ms']} ms), whose ceiling is priced on PMC "
+                           "bytes that were not collected for this library build; reported instead: the longest kernel with an "
+                           "event-timed rate")
         top["traffic_source"] = traffic_note
         top["kernels"] = ks
         top["whole_step"] = whole

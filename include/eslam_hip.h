@@ -334,6 +334,11 @@ int eslam_keep_best(const float* loss, const float* pose, int n, float* best, fl
  * (integer adds commute), so every output of the path is bitwise reproducible from run to run, at a lower speed.
  * eslam_loss_scratch_reset: back to the freshly-zeroed state, e.g. after a graph was aborted mid-flight.             */
 int eslam_deterministic(void);
+
+/* Host-side helper of the Python layer (no reference counterpart): `waiter` waits for the work enqueued on `signaler` so
+ * far - the fork / join of the side stream the ray ordering (eslam_ray_order, what the backward's scatter bundles by) runs
+ * on beside the samplers and the forward kernel.  One hipEventRecord + hipStreamWaitEvent; valid inside a stream capture. */
+int eslam_stream_wait(eslam_stream_t waiter, eslam_stream_t signaler);
 int64_t eslam_loss_scratch_floats(int64_t n_rays);
 int eslam_loss_scratch_reset(float* scratch, int64_t floats, eslam_stream_t stream);
 int eslam_loss_value(const float* depth, const float* rgb, const float* sdf, const float* z_vals,

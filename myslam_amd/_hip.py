@@ -56,6 +56,7 @@ SIGNATURES = {
     "eslam_planes_to_half": (_i, [_PP, _vp]),
     "eslam_render_fwd_lowp": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "eslam_ray_order": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "eslam_stream_wait": (_i, [_vp, _vp]),
     "eslam_bwd_workspace_bytes": (_i64, [_i64]),
     "eslam_render_bwd": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                               _vp, _vp, _vp, _vp]),
@@ -150,6 +151,21 @@ def stream_handle(device):
     if _raw_stream is not None and device.index is not None:
         return ctypes.c_void_p(_raw_stream(device.index))
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+_TORCH_STREAM_WAIT = os.environ.get("ESLAM_TORCH_STREAM_WAIT", "0") == "1"
+
+
+def stream_wait(device, waiter, signaler):
+    """waiter / signaler: torch.cuda.Stream, or None for the caller's current stream on `device`."""
+    if _TORCH_STREAM_WAIT:          # A/B switch (ESLAM_TORCH_STREAM_WAIT=1): torch's own Stream.wait_stream
+        (torch.cuda.current_stream(device) if waiter is None else waiter).wait_stream(
+            torch.cuda.current_stream(device) if signaler is None else signaler)
+        return
+    w = stream_handle(device) if waiter is None else ctypes.c_void_p(waiter.cuda_stream)
+    s = stream_handle(device) if signaler is None else ctypes.c_void_p(signaler.cuda_stream)
+    with on_device(device):
+        check(lib().eslam_stream_wait(w, s), "eslam_stream_wait")
 
 
 class _NullCtx:

@@ -136,9 +136,8 @@ def ray_order_async(rays_o, rays_d):
     if side is None:
         side = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
     perm = torch.empty(R, dtype=torch.int32, device=dev)
-    cur = torch.cuda.current_stream(dev)
-    side.wait_stream(cur)
-    with _hip.on_device(dev), torch.cuda.stream(side):
+    _hip.stream_wait(dev, side, None)           # the rays come from work on the caller's stream
+    with _hip.on_device(dev):
         _hip.check(_hip.lib().eslam_ray_order(_hip.ptr(ro), _hip.ptr(rd), R, _hip.ptr(perm),
                                               ctypes.c_void_p(side.cuda_stream)), "eslam_ray_order")
     perm.record_stream(side)
@@ -238,7 +237,7 @@ def join_ray_order(device):
     captures forward and backward into SEPARATE hipGraphs must join inside the forward's capture (parallel.py)."""
     side = _side_streams.get(torch.device(device).index)
     if side is not None:
-        torch.cuda.current_stream(device).wait_stream(side)
+        _hip.stream_wait(torch.device(device), None, side)
 
 
 # In-kernel random numbers of the samplers (eslam_sample_z_all_rng): a step counter per device, read by the sampler and
@@ -296,7 +295,7 @@ class RenderFn(torch.autograd.Function):
         if order_in is not None:
             order, side = order_in
             if _FWD_USES_ORDER:
-                torch.cuda.current_stream(dev).wait_stream(side)
+                _hip.stream_wait(dev, None, side)
                 side = None
             # otherwise only the backward needs the order: the ordering kernel (side stream) is joined there, and the
             # forward kernel starts as soon as the samplers are done
@@ -310,8 +309,8 @@ class RenderFn(torch.autograd.Function):
             # the ray-order side stream, beside the forward kernel; joined in the backward with the order itself
             nbytes = lib.eslam_scatter_records_bytes(R, S)
             records = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))          # z_vals come from the samplers on this stream
-            with _hip.on_device(dev), torch.cuda.stream(side):
+            _hip.stream_wait(dev, side, None)          # z_vals come from the samplers on this stream
+            with _hip.on_device(dev):
                 _hip.check(lib.eslam_scatter_prep(arr, _hip.make_bound(bound6), _hip.ptr(rays_o), _hip.ptr(rays_d),
                                                   _hip.ptr(z_vals), R, S, _hip.ptr(order), _hip.ptr(records),
                                                   ctypes.c_void_p(side.cuda_stream)), "eslam_scatter_prep")
@@ -347,7 +346,7 @@ class RenderFn(torch.autograd.Function):
         if order_in is not None and side is not None:
             # join the side stream (ray order, scatter records) BEHIND the forward kernel: the work beside it has overlapped,
             # and no fork is left dangling if this forward is never followed by a backward (or sits in a graph of its own)
-            torch.cuda.current_stream(dev).wait_stream(side)
+            _hip.stream_wait(dev, None, side)
             side = None
         if needs:
             ctx.bound6 = bound6
@@ -367,7 +366,7 @@ class RenderFn(torch.autograd.Function):
         dev = rays_o.device
         lib = _hip.lib()
         if getattr(ctx, "order_stream", None) is not None:
-            torch.cuda.current_stream(dev).wait_stream(ctx.order_stream)      # join the ordering kernel
+            _hip.stream_wait(dev, None, ctx.order_stream)      # join the ordering kernel
             ctx.order_stream = None
         need = ctx.needs_input_grad
         L = RenderFn.N_LEAD

@@ -356,7 +356,7 @@ def test_bench_line_contract():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
     assert 0.0 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) <= 1e-9
-    for kern in rf["kernels"]:
-        assert 0.0 < kern["frac"] <= 1.0, kern
+    for kern in rf["kernels"]:          # (the scatter's and the decoder backward's need the PMC bytes of this very build)
+        assert kern["frac"] is None or 0.0 < kern["frac"] <= 1.0, kern
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == d["unit"] and cb["sample"]
