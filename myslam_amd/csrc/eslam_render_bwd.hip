@@ -101,6 +101,9 @@ struct RayBwdIn {                  // MODE >= 1: what the composite backward of 
 // LOWP: the mixed-precision tile (eslam_decode_tile.h): hidden layers recomputed and every product of the backward pass on
 // bf16 MFMA (16x16x32 / 16x16x16) with float32 accumulation - 15 MFMAs of 16 cycles per 16 points and decoder instead of
 // 68 of 32 cycles; features, activations' masks, biases and all accumulators stay float32.
+#ifndef BWD_ABLATE
+#define BWD_ABLATE 0      // profiling only (make variant VFLAGS=-DBWD_ABLATE=n): 1 no g_feat stores, 2 no weight gradients, 4 no feature loads
+#endif
 template <int MODE, bool WGRAD, bool LOWP>
 __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t dec, const float* __restrict__ feat,
                                                       const float* __restrict__ g_o, int64_t N,
@@ -177,6 +180,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
                 v[2] = v[3] = (float4_t){0.f, 0.f, 0.f, 0.f};
                 return;
             }
+            if (BWD_ABLATE & 4) { v[0] = v[1] = v[2] = v[3] = (float4_t){0.1f, 0.2f, -0.1f, 0.3f}; return; }
             const float* fp = feat + pt * 128 + d * 64 + 4 * gq;     // piece gq = channels 4gq.., 16+4gq.. of a level
             v[0] = *(const float4_t*)(fp);
             v[1] = *(const float4_t*)(fp + 16);
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
                 for (int ks = 0; ks < 4; ++ks) {
                     const int64_t pk = min(p0 + 16 * b + 4 * q + ks, N - 1);
                     if (LOWP) fbkp[ks] = *(const short4_t*)((const short*)feat + pk * 128 + d * 64 + 4 * r);
-                    else fbk[ks] = *(const float4_t*)(feat + pk * 128 + d * 64 + 4 * r);
+                    else fbk[ks] = (BWD_ABLATE & 4) ? (float4_t){0.1f, 0.2f, 0.3f, 0.4f} : *(const float4_t*)(feat + pk * 128 + d * 64 + 4 * r);
                 }
             }
             if (LOWP) to_mfma_role<true, 8>(ft, lane);       // 8 registers of packed bf16 pairs
@@ -279,9 +283,9 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
                 for (int i = 0; i < 4; ++i) gf[(mb >> 1) * 8 + 4 * (mb & 1) + i] = acc[i];
             }
             to_gather_role<true, 16>(gf, lane);
-            if (p0 + 16 * b + gp < p0 + nvalid) store_features(g_feat, p0 + 16 * b + gp, d, gq, gf);
+            if (!(BWD_ABLATE & 1) && p0 + 16 * b + gp < p0 + nvalid) store_features(g_feat, p0 + 16 * b + gp, d, gq, gf);
             }
-            if (!WGRAD) continue;
+            if (!WGRAD || (BWD_ABLATE & 2)) continue;
 
             // transposes through LDS: D layout (rows 4q+reg, col = point r) -> [point][row]
             *(float4_t*)(tz1 + r * TP + 4 * q) = gz1;
