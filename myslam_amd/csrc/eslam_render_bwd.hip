@@ -77,6 +77,10 @@ __global__ void decode_act_bwd_kernel(const float* __restrict__ raw, const float
 // and - when the loss is the fused mapping loss - the loss gradient formed in the same wave
 // ---------------------------------------------------------------------------------------------------------
 #define TP 20                      // row pitch (floats) of the 16x16 transpose tiles: conflict-free, 16-B aligned
+#define TPF 68                     // row pitch of the 16-point x 64-feature tile (float32 path)
+#ifndef BWD_FBK_LDS
+#define BWD_FBK_LDS 1              // A/B switch: 0 = re-read the block's feature rows from global memory for the g_W1 contraction
+#endif
 
 struct RayBwdIn {                  // MODE >= 1: what the composite backward of a ray reads
     const float* z_vals;           // [R,S]
@@ -112,6 +116,8 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
     __shared__ __attribute__((aligned(16))) float wlds[2 * DEC_LDS];
     __shared__ __attribute__((aligned(16))) float tiles[4][4][16 * TP];   // per wave: gz1, gz2, h1, h2 (as [pt][j])
     __shared__ __attribute__((aligned(16))) float gtile[4][64 * 4];       // per wave: g_o of the tile [pt][o]
+    // per wave: the block's features [pt][feature] for the g_W1 contraction (float32 path, BWD_FBK_LDS)
+    __shared__ __attribute__((aligned(16))) float ftile[(WGRAD && !LOWP && BWD_FBK_LDS) ? 4 : 1][(WGRAD && !LOWP && BWD_FBK_LDS) ? 16 * TPF : 4];
     if (LOWP) stage_decoder_weights_lowp(wlds, dec, threadIdx.x, blockDim.x);
     else stage_decoder_weights(wlds, dec, threadIdx.x, blockDim.x);
     __syncthreads();
@@ -196,12 +202,21 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
             for (int i = 0; i < 4; ++i) {
                 ft[i] = fnext[0][i]; ft[4 + i] = fnext[1][i]; ft[8 + i] = fnext[2][i]; ft[12 + i] = fnext[3][i];
             }
-            if (b + 1 < nblk) load_block(b + 1, fnext);
+            if (b + 1 < nblk) load_block(b + 1, fnext);       // (two blocks ahead: 250 VGPRs, no faster)
             // the same rows again in the "feature on the lane" layout of the g_W1 contraction (B operand): requested
             // here so that the L1/L2 latency is covered by the 28 MFMAs of the recompute instead of stalling them later
+            // float32 path: NOT re-read from memory but handed over through a wave-private LDS tile, written here in the
+            // gather role and read back just before the contraction.  The global re-read (L1 / L2 hits) was waited for in the
+            // middle of the block - behind the previous block's four feature-gradient stores, a wave's loads and stores
+            // retiring in order - which exposed those stores' latency in every block (15 us of this kernel at 4096 x 64).
+            constexpr bool FBK_LDS = WGRAD && !LOWP && BWD_FBK_LDS != 0;
             float4_t fbk[4];
             short4_t fbkp[4];
-            if (WGRAD) {
+            if (FBK_LDS) {
+                float* T = ftile[wave] + gp * TPF + 4 * gq;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *(float4_t*)(T + 16 * j) = (float4_t){ft[4 * j], ft[4 * j + 1], ft[4 * j + 2], ft[4 * j + 3]};
+            } else if (WGRAD) {
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const int64_t pk = min(p0 + 16 * b + 4 * q + ks, N - 1);
@@ -322,6 +337,10 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
                 gW3 = mfma16(ago[ks], bh2[ks], gW3);              // g_W3[o][j]  : rows o = 4q+reg (q = 0), col j = r
             }
             // g_W1[j][f]: B = features of point 4q+ks, columns permuted: column c of n-block nb <-> feature 4c + nb
+            if (FBK_LDS) {      // (the tile was written before this block's first WAVE_SYNC)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) fbk[ks] = *(const float4_t*)(ftile[wave] + (4 * q + ks) * TPF + 4 * r);
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
