@@ -77,7 +77,8 @@ __global__ void decode_act_bwd_kernel(const float* __restrict__ raw, const float
 // and - when the loss is the fused mapping loss - the loss gradient formed in the same wave
 // ---------------------------------------------------------------------------------------------------------
 #define TP 20                      // row pitch (floats) of the 16x16 transpose tiles: conflict-free, 16-B aligned
-#define TPF 68                     // row pitch of the 16-point x 64-feature tile (float32 path)
+#define TPF 68                     // row pitch of the 16-point x 64-feature tile (floats)
+#define TPH 72                     // the same tile in bf16 (shorts): 144-byte rows keep the 16-byte writes aligned
 #ifndef BWD_FBK_LDS
 #define BWD_FBK_LDS 1              // A/B switch: 0 = re-read the block's feature rows from global memory for the g_W1 contraction
 #endif
@@ -116,8 +117,8 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
     __shared__ __attribute__((aligned(16))) float wlds[2 * DEC_LDS];
     __shared__ __attribute__((aligned(16))) float tiles[4][4][16 * TP];   // per wave: gz1, gz2, h1, h2 (as [pt][j])
     __shared__ __attribute__((aligned(16))) float gtile[4][64 * 4];       // per wave: g_o of the tile [pt][o]
-    // per wave: the block's features [pt][feature] for the g_W1 contraction (float32 path, BWD_FBK_LDS)
-    __shared__ __attribute__((aligned(16))) float ftile[(WGRAD && !LOWP && BWD_FBK_LDS) ? 4 : 1][(WGRAD && !LOWP && BWD_FBK_LDS) ? 16 * TPF : 4];
+    // per wave: the block's features [pt][feature] for the g_W1 contraction (BWD_FBK_LDS): float32, or bf16 at half the pitch
+    __shared__ __attribute__((aligned(16))) float ftile[(WGRAD && BWD_FBK_LDS) ? 4 : 1][(WGRAD && BWD_FBK_LDS) ? (LOWP ? 16 * TPH / 2 : 16 * TPF) : 4];
     if (LOWP) stage_decoder_weights_lowp(wlds, dec, threadIdx.x, blockDim.x);
     else stage_decoder_weights(wlds, dec, threadIdx.x, blockDim.x);
     __syncthreads();
@@ -209,10 +210,14 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
             // gather role and read back just before the contraction.  The global re-read (L1 / L2 hits) was waited for in the
             // middle of the block - behind the previous block's four feature-gradient stores, a wave's loads and stores
             // retiring in order - which exposed those stores' latency in every block (15 us of this kernel at 4096 x 64).
-            constexpr bool FBK_LDS = WGRAD && !LOWP && BWD_FBK_LDS != 0;
+            constexpr bool FBK_LDS = WGRAD && BWD_FBK_LDS != 0;
             float4_t fbk[4];
             short4_t fbkp[4];
-            if (FBK_LDS) {
+            if (FBK_LDS && LOWP) {          // bf16: the lane holds channels 8gq..8gq+7 of each level as 4 + 4 floats' worth of bits
+                short* T = (short*)ftile[wave] + gp * TPH + 8 * gq;
+                *(float4_t*)(T) = (float4_t){ft[0], ft[1], ft[2], ft[3]};
+                *(float4_t*)(T + 32) = (float4_t){ft[4], ft[5], ft[6], ft[7]};
+            } else if (FBK_LDS) {
                 float* T = ftile[wave] + gp * TPF + 4 * gq;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) *(float4_t*)(T + 16 * j) = (float4_t){ft[4 * j], ft[4 * j + 1], ft[4 * j + 2], ft[4 * j + 3]};
@@ -326,6 +331,10 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
                 gW3 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pack4(ago[0], ago[1], ago[2], ago[3]),
                                                                 pack4(bh2[0], bh2[1], bh2[2], bh2[3]), gW3, 0, 0, 0);
                 const short4_t a1p = pack4(az1[0], az1[1], az1[2], az1[3]);
+                if (FBK_LDS) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) fbkp[ks] = *(const short4_t*)((const short*)ftile[wave] + (4 * q + ks) * TPH + 4 * r);
+                }
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb)
                     gW1[nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1p, (short4_t){fbkp[0][nb], fbkp[1][nb], fbkp[2][nb], fbkp[3][nb]},
