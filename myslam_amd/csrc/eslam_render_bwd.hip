@@ -79,6 +79,9 @@ __global__ void decode_act_bwd_kernel(const float* __restrict__ raw, const float
 #define TP 20                      // row pitch (floats) of the 16x16 transpose tiles: conflict-free, 16-B aligned
 #define TPF 68                     // row pitch of the 16-point x 64-feature tile (floats)
 #define TPH 72                     // the same tile in bf16 (shorts): 144-byte rows keep the 16-byte writes aligned
+#ifndef BWD_STAMPS
+#define BWD_STAMPS 0             // profiling only: per-phase cycle counts (s_memtime) of one wave per decoder, printed at the end
+#endif
 #ifndef BWD_FBK_LDS
 #define BWD_FBK_LDS 1              // A/B switch: 0 = re-read the block's feature rows from global memory for the g_W1 contraction
 #endif
@@ -167,6 +170,12 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
     gW2 = gW3 = gb1 = gb2 = (float4_t){0.f, 0.f, 0.f, 0.f};
     float gb3[3] = {0.f, 0.f, 0.f};
     float gbeta_acc = 0.0f;
+#if BWD_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = clock64();
+#define STAMP(i) { const unsigned long long now_ = clock64(); st_acc[i] += now_ - st_last; st_last = now_; }
+#else
+#define STAMP(i)
+#endif
 
     // MLP backward of one tile of <= 64 points starting at point p0; go[] = this decoder's pre-activation output
     // gradients of the lane's point (sample role)
@@ -229,6 +238,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
                     else fbk[ks] = (BWD_ABLATE & 4) ? (float4_t){0.1f, 0.2f, 0.3f, 0.4f} : *(const float4_t*)(feat + pk * 128 + d * 64 + 4 * r);
                 }
             }
+            STAMP(1)
             if (LOWP) to_mfma_role<true, 8>(ft, lane);       // 8 registers of packed bf16 pairs
             else to_mfma_role<true, 16>(ft, lane);
             float4_t h1, h2, gz1, gz2;
@@ -276,6 +286,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
                 }
             } else {
             mlp_hidden(f, ft, h1, h2);
+            STAMP(2)
 
             // g_h2^T = W3^T . g_o^T   (K = (block', o); only block' == b contributes)
             float4_t gh2 = (float4_t){0.f, 0.f, 0.f, 0.f};
@@ -302,9 +313,11 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) gf[(mb >> 1) * 8 + 4 * (mb & 1) + i] = acc[i];
             }
+            STAMP(3)
             to_gather_role<true, 16>(gf, lane);
             if (!(BWD_ABLATE & 1) && p0 + 16 * b + gp < p0 + nvalid) store_features(g_feat, p0 + 16 * b + gp, d, gq, gf);
             }
+            STAMP(4)
             if (!WGRAD || (BWD_ABLATE & 2)) continue;
 
             // transposes through LDS: D layout (rows 4q+reg, col = point r) -> [point][row]
@@ -325,6 +338,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
                 bh2[ks] = th2[prow * TP + r];
                 ago[ks] = (r < 4) ? gt[(16 * b + prow) * 4 + r] : 0.0f;
             }
+            STAMP(5)
             if (LOWP) {      // the same contractions over the block's 16 points, K = 16 in one bf16 MFMA each
                 gW2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pack4(az2[0], az2[1], az2[2], az2[3]),
                                                                 pack4(bh1[0], bh1[1], bh1[2], bh1[3]), gW2, 0, 0, 0);
@@ -357,6 +371,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
             }
             }
             WAVE_SYNC();
+            STAMP(6)
         }
     };
 
@@ -404,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
             x.mask = 1;
             if (MODE == 2) {
                 x.gtd = li.gt_depth[ray];
-                x.mask = li.ray_mask ? (li.ray_mask[ray] != 0) : 1;
+                x.mask = li.ray_mask ? (int)li.ray_mask[ray] : 1;      // the byte as loaded: comparing it here would wait for it here
                 x.dep = li.depth[ray];
                 x.cr = li.rgb[3 * ray + 0]; x.cg = li.rgb[3 * ray + 1]; x.cb = li.rgb[3 * ray + 2];
                 x.tr = li.gt_color[3 * ray + 0]; x.tg = li.gt_color[3 * ray + 1]; x.tb = li.gt_color[3 * ray + 2];
@@ -465,11 +480,13 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
                 const ChunkIn ch = (c == nchunk - 1) ? cin : load_chunk(ray, c);
                 float gs = ch.gs;
                 if (MODE == 2 && valid) gs += loss_g_sdf(m, ch.z, ch.sd, gtd, li.tr, lk);
+                STAMP(7)
                 const float4_t o = composite_bwd_chunk(up, beta, valid, ch.sd, ch.z, ch.cr, ch.cg, ch.cb, gs, trans_in, carry,
                                                        gbeta_acc, lane);
                 float go[4] = {0.f, 0.f, 0.f, 0.f};
                 if (d == 0) go[0] = o[3];
                 else { go[0] = o[0]; go[1] = o[1]; go[2] = o[2]; }
+                STAMP(0)
                 tile_bwd(base + c * WAVE, min(WAVE, S - c * WAVE), go);
             }
             rin = rnx;
@@ -485,6 +502,12 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
             rb.beta_parts[blockIdx.x] = (beta_part[0] + beta_part[1]) + (beta_part[2] + beta_part[3]);
     }
 
+#if BWD_STAMPS
+    if (blockIdx.x == 5 && threadIdx.x == 0)
+        printf("stamps d=%d cycles: composite %llu | top of a block (wait for its feature rows) %llu | recompute issue %llu | backward mfma issue %llu | "
+               "role change + stores (waits for the MFMA chain) %llu | lds transposes %llu | weight gradients %llu | ray prologue %llu\n",
+               d, st_acc[0], st_acc[1], st_acc[2], st_acc[3], st_acc[4], st_acc[5], st_acc[6], st_acc[7]);
+#endif
     if (!WGRAD) return;
     // the four waves' partial parameter gradients are summed in LDS; one slab row per workgroup: [wg][decoder][SLAB]
     __shared__ __attribute__((aligned(16))) float comb[4][SLAB];
