@@ -260,6 +260,9 @@ __global__ __launch_bounds__(1024) void ray_order_kernel(const float* __restrict
 //   PHASE 1 (eslam_scatter_prep) stops after the sort and writes the workgroup's sorted record image (the 6*BM words of
 //   LDS + one word of flags) to `records`; PHASE 2 (inside eslam_render_bwd) reads that image back - 48 KB of coalesced
 //   loads instead of 33 us of latency-bound cell arithmetic and sorting in front of the first atomic - and walks it.
+#ifndef SC_STAMPS
+#define SC_STAMPS 0                                   // profiling only: per-phase cycles of one workgroup's first thread
+#endif
 #define REC_META 4                                   // words behind the LDS image: [0] = swap | valid << 1
 //   DET (ESLAM_DETERMINISTIC=1): the sums of a cell are formed in 64-bit fixed point (2^-44 units: integer adds commute, so
 //   neither the arbitrary order of the counting sort's tickets inside a cell, nor the order in which workgroups' atomics
@@ -345,6 +348,12 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
     const int nu = min(bundle, nunits - u0);
     const int n = nu * per;                                           // <= BM by construction of `bundle`
 
+#if SC_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = clock64();
+#define SSTAMP(i) { const unsigned long long now_ = clock64(); st_acc[i] += now_ - st_last; st_last = now_; }
+#else
+#define SSTAMP(i)
+#endif
     unsigned* const rimg = (PHASE != 0) ? records + ((size_t)bidx * NPL + pi) * (6 * BM + REC_META) : nullptr;
     bool swap = false;
     if (PHASE == 2) {
@@ -391,6 +400,7 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
             }
         }
     }
+    SSTAMP(0)
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         bx0 = min(bx0, __shfl_xor(bx0, m, WAVE)); bx1 = max(bx1, __shfl_xor(bx1, m, WAVE));
@@ -418,6 +428,7 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
     const int mmin = swap ? bymin : bxmin, mext = (swap ? bymax : bxmax) - mmin + 2;
     const int Mmin = swap ? bxmin : bymin, Mext = (swap ? bxmax : bymax) - Mmin + 1;
     const bool counting = allow_counting && (int64_t)mext * Mext <= 4 * BM;
+    SSTAMP(1)
     if (counting) {
         constexpr int WPT = 2 * BM / NT;                       // counter words per thread in the scan
         for (int i = threadIdx.x; i < 2 * BM; i += NT) cnt[i] = 0u;
@@ -434,6 +445,7 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
             }
         }
         __syncthreads();
+        SSTAMP(2)
         // exclusive scan of the counters: thread t owns words [WPT t, WPT t + WPT)
         unsigned w[WPT], local = 0;
 #pragma unroll
@@ -461,6 +473,7 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
             run += lo16 + hi16;
         }
         __syncthreads();
+        SSTAMP(3)
         unsigned pos[SPT];
 #pragma unroll
         for (int k = 0; k < SPT; ++k) pos[k] = ((cnt[loc[k] >> 1] >> ((loc[k] & 1u) * 16u)) & 0xFFFFu) + tick[k];
@@ -569,6 +582,7 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
         return;
     }
     }       // PHASE != 2
+    SSTAMP(4)
     if (dbg_mode == 2) return;
 
     // (3) walk: wave w owns sorted entries [256w, 256w+256), 64 at a time.  Per 64-entry block every lane fetches ONE
@@ -690,6 +704,12 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
 #undef LOAD_HALF
 #undef WALK_HALF
     flush(false);
+    SSTAMP(5)
+#if SC_STAMPS
+    if (bid == 400 && threadIdx.x == 0)
+        printf("scatter stamps (cycles): cells %llu | box %llu | zero+tickets %llu | scan %llu | placement %llu | walk %llu\n", st_acc[0], st_acc[1],
+               st_acc[2], st_acc[3], st_acc[4], st_acc[5]);
+#endif
 }
 
 // deterministic mode: float gradient += shadow * 2^-44, shadow cleared (it is all zero again for the next call)
