@@ -120,20 +120,58 @@ __device__ __forceinline__ int opaque_zero(int loop_var) {
     return z;
 }
 
+// Wave-wide sums and prefix products run on DPP (data-parallel primitives: the operand of a VALU instruction comes from
+// another lane of the same 16-lane row, or - row_bcast - from the last lane of the previous row / half), ~10 cycles a step,
+// instead of __shfl_* (ds_bpermute_b32 through the LDS crossbar, ~60-100 cycles a step when each step waits for the last):
+// a ray's epilogue in the forward kernel alone is 15 such reductions.  The six steps are LLVM's own lowering of a wave64
+// scan on gfx9 (row_shr 1, 2, 4, 8, then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).
+// All 64 lanes must be active (as for __shfl_*).  Profiling switch: -DESLAM_NO_DPP restores the __shfl_* forms.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_from(float ident, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ident), __builtin_bit_cast(int, v), CTRL,
+                                                                 ROW_MASK, 0xf, false));
+}
+
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ float wave_incl_sum(float v) {
+    v += dpp_from<0x111, 0xf>(0.0f, v);
+    v += dpp_from<0x112, 0xf>(0.0f, v);
+    v += dpp_from<0x114, 0xf>(0.0f, v);
+    v += dpp_from<0x118, 0xf>(0.0f, v);
+    v += dpp_from<0x142, 0xa>(0.0f, v);
+    v += dpp_from<0x143, 0xc>(0.0f, v);
+    return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
+#ifdef ESLAM_NO_DPP
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, WAVE);
     return v;
+#else
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_incl_sum(v)), WAVE - 1));
+#endif
 }
 
 // inclusive product scan over the 64 lanes of a wave
 __device__ __forceinline__ float wave_incl_prod(float v, int lane) {
+#ifdef ESLAM_NO_DPP
 #pragma unroll
     for (int d = 1; d < WAVE; d <<= 1) {
         float o = __shfl_up(v, d, WAVE);
         if (lane >= d) v *= o;
     }
     return v;
+#else
+    (void)lane;
+    v *= dpp_from<0x111, 0xf>(1.0f, v);
+    v *= dpp_from<0x112, 0xf>(1.0f, v);
+    v *= dpp_from<0x114, 0xf>(1.0f, v);
+    v *= dpp_from<0x118, 0xf>(1.0f, v);
+    v *= dpp_from<0x142, 0xa>(1.0f, v);
+    v *= dpp_from<0x143, 0xc>(1.0f, v);
+    return v;
+#endif
 }
 
 // inclusive suffix sum (lane i gets sum over lanes >= i)
