@@ -174,14 +174,76 @@ __device__ __forceinline__ float wave_incl_prod(float v, int lane) {
 #endif
 }
 
-// inclusive suffix sum (lane i gets sum over lanes >= i)
+// inclusive suffix sum (lane i gets sum over lanes >= i): row_shl steps inside the 16-lane rows, then the totals of the later
+// rows (lane 0 of a row holds its row's total) added through the scalar unit - DPP has no broadcast in this direction
 __device__ __forceinline__ float wave_incl_suffix_sum(float v, int lane) {
+#ifdef ESLAM_NO_DPP
 #pragma unroll
     for (int d = 1; d < WAVE; d <<= 1) {
         float o = __shfl_down(v, d, WAVE);
         if (lane + d < WAVE) v += o;
     }
     return v;
+#else
+    v += dpp_from<0x101, 0xf>(0.0f, v);
+    v += dpp_from<0x102, 0xf>(0.0f, v);
+    v += dpp_from<0x104, 0xf>(0.0f, v);
+    v += dpp_from<0x108, 0xf>(0.0f, v);
+    const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float t2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float t3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    const int row = lane >> 4;
+    return v + (row == 0 ? t1 + (t2 + t3) : row == 1 ? t2 + t3 : row == 2 ? t3 : 0.0f);
+#endif
+}
+
+// lane i <- lane i-1 (lane 0 <- first) / lane i <- lane i+1 (lane 63 <- last); one value of a fixed lane in every lane
+__device__ __forceinline__ float wave_up1(float v, float first) {
+#ifdef ESLAM_NO_DPP
+    const float o = __shfl_up(v, 1, WAVE);
+    return (threadIdx.x & (WAVE - 1)) == 0 ? first : o;
+#else
+    return dpp_from<0x138, 0xf>(first, v);          // wave_shr:1
+#endif
+}
+__device__ __forceinline__ float wave_down1(float v, float last) {
+#ifdef ESLAM_NO_DPP
+    const float o = __shfl_down(v, 1, WAVE);
+    return (threadIdx.x & (WAVE - 1)) == WAVE - 1 ? last : o;
+#else
+    return dpp_from<0x130, 0xf>(last, v);           // wave_shl:1
+#endif
+}
+template <int LANE>
+__device__ __forceinline__ float wave_lane(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), LANE));
+}
+
+// integer forms for the scatter's sort phases: min / max over the wave (every lane gets the result), inclusive prefix sum
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_from_i(int ident, int v) {
+    return __builtin_amdgcn_update_dpp(ident, v, CTRL, ROW_MASK, 0xf, false);
+}
+#define ESLAM_DPP_REDUCE_I(v, OP, IDENT)                 \
+    v = OP(v, dpp_from_i<0x111, 0xf>(IDENT, v));         \
+    v = OP(v, dpp_from_i<0x112, 0xf>(IDENT, v));         \
+    v = OP(v, dpp_from_i<0x114, 0xf>(IDENT, v));         \
+    v = OP(v, dpp_from_i<0x118, 0xf>(IDENT, v));         \
+    v = OP(v, dpp_from_i<0x142, 0xa>(IDENT, v));         \
+    v = OP(v, dpp_from_i<0x143, 0xc>(IDENT, v));
+__device__ __forceinline__ int wave_min_i(int v) {
+    ESLAM_DPP_REDUCE_I(v, min, 0x7FFFFFFF)
+    return __builtin_amdgcn_readlane(v, WAVE - 1);
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+    ESLAM_DPP_REDUCE_I(v, max, (int)0x80000000)
+    return __builtin_amdgcn_readlane(v, WAVE - 1);
+}
+__device__ __forceinline__ int iadd_(int a, int b) { return a + b; }
+__device__ __forceinline__ unsigned wave_incl_sum_u(unsigned x) {
+    int v = (int)x;
+    ESLAM_DPP_REDUCE_I(v, iadd_, 0)
+    return (unsigned)v;
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -27,8 +27,7 @@ __device__ __forceinline__ float4_t composite_bwd_chunk(const RayUp up, float be
     const float alpha = valid ? 1.0f - e : 0.0f;
     const float fac = valid ? (1.0f - alpha) + 1e-10f : 1.0f;
     const float pin = wave_incl_prod(fac, lane);
-    float pex = __shfl_up(pin, 1, WAVE);
-    if (lane == 0) pex = 1.0f;
+    const float pex = wave_up1(pin, 1.0f);
     const float T = trans_in * pex;
     const float w = alpha * T;
     const float gw = up.gd * z + up.gr * cr + up.gg * cg + up.gb * cb;
@@ -36,12 +35,11 @@ __device__ __forceinline__ float4_t composite_bwd_chunk(const RayUp up, float be
     // exclusive suffix sum_{k>i} gw_k w_k, formed WITHOUT subtracting v_i from an inclusive sum: w decays
     // geometrically along the ray, so (inclusive - own) would lose the small tail in the rounding of the
     // dominant own term, and g_alpha is itself a cancelling difference of two terms of the size of gw.
-    float vn = __shfl_down(v, 1, WAVE);
-    if (lane == WAVE - 1) vn = 0.0f;
+    const float vn = wave_down1(v, 0.0f);
     const float after_local = wave_incl_suffix_sum(vn, lane);
     const float after = after_local + carry;
     const float g_alpha = gw * T - after / fac;
-    carry += __shfl(after_local, 0, WAVE) + __shfl(v, 0, WAVE);
+    carry += wave_lane<0>(after_local) + wave_lane<0>(v);
     float4_t o = (float4_t){0.f, 0.f, 0.f, 0.f};
     if (valid) {
         const float ds = sg * (1.0f - sg);                // sigmoid'
@@ -468,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
                 const int s = c * WAVE + lane;               // chunks before the last are full
                 const float sd = rb.sdf[base + s];
                 const float alpha = 1.0f - expf(-beta * sigmoidf_(-sd * beta));
-                const float cp = __shfl(wave_incl_prod((1.0f - alpha) + 1e-10f, lane), 63, WAVE);
+                const float cp = wave_lane<63>(wave_incl_prod((1.0f - alpha) + 1e-10f, lane));
                 if (lane == c) myprod = cp;
             }
             // pass B: chunks in reverse, carrying the suffix sum of gw*w

@@ -175,14 +175,13 @@ __global__ __launch_bounds__(256, FWD_WAVES) void render_fwd_kernel(const PlaneS
         if (!valid) alpha = 0.0f;
         const float fac = valid ? (1.0f - alpha) + 1e-10f : 1.0f;
         const float pin = wave_incl_prod(fac, lane);
-        float pex = __shfl_up(pin, 1, WAVE);
-        if (lane == 0) pex = 1.0f;
+        const float pex = wave_up1(pin, 1.0f);
         const float w = alpha * (trans_in * pex);
         acc_depth += wave_sum(w * z);
         acc_r += wave_sum(w * cr);
         acc_g += wave_sum(w * cg);
         acc_b += wave_sum(w * cb);
-        trans_in *= __shfl(pin, 63, WAVE);
+        trans_in *= wave_lane<63>(pin);
         if (LOSS && valid && has_depth) {              // Mapper.py:124-140
             const int reg = sdf_region(z, gtd, li.tr);
             if (reg == 0) { lv[A_N_FRONT] += 1.0f; const float e = sdf - 1.0f; lv[A_S_FRONT] += e * e; }

@@ -343,10 +343,9 @@ __global__ __launch_bounds__(256, 2) void importance_z_kernel(const PlaneSet pla
         const float alpha = valid ? al[c0 + lane] : 0.0f;
         const float fac = valid ? (1.0f - alpha) + 1e-10f : 1.0f;
         const float pin = wave_incl_prod(fac, lane);
-        float pex = __shfl_up(pin, 1, WAVE);
-        if (lane == 0) pex = 1.0f;
+        const float pex = wave_up1(pin, 1.0f);
         if (valid) wt[c0 + lane] = alpha * (trans_in * pex);
-        trans_in *= __shfl(pin, 63, WAVE);
+        trans_in *= wave_lane<63>(pin);
     }
     WAVE_SYNC();
 

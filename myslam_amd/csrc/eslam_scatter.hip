@@ -401,11 +401,8 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
         }
     }
     SSTAMP(0)
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        bx0 = min(bx0, __shfl_xor(bx0, m, WAVE)); bx1 = max(bx1, __shfl_xor(bx1, m, WAVE));
-        by0 = min(by0, __shfl_xor(by0, m, WAVE)); by1 = max(by1, __shfl_xor(by1, m, WAVE));
-    }
+    bx0 = wave_min_i(bx0); bx1 = wave_max_i(bx1);
+    by0 = wave_min_i(by0); by1 = wave_max_i(by1);
     if (lane == 0) {
         atomicMin(&sbox[0], bx0); atomicMax(&sbox[1], bx1);
         atomicMin(&sbox[2], by0); atomicMax(&sbox[3], by1);
@@ -453,12 +450,7 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
             w[j] = cnt[threadIdx.x * WPT + j];
             local += (w[j] & 0xFFFFu) + (w[j] >> 16);
         }
-        unsigned incl = local;
-#pragma unroll
-        for (int dlt = 1; dlt < WAVE; dlt <<= 1) {
-            const unsigned up = __shfl_up(incl, dlt, WAVE);
-            if (lane >= dlt) incl += up;
-        }
+        const unsigned incl = wave_incl_sum_u(local);
         if (lane == WAVE - 1) swsum[wave] = incl;
         __syncthreads();
         unsigned run = incl - local, nvalid = 0;
