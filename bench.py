@@ -307,7 +307,7 @@ def roofline(prof, n, ms_step):
                                        "algorithmic_bytes_per_launch")}
         if dom is not longest:
             top["note"] = (f"the longest kernel is {longest['kernel']} ({longest['avg_kernel_ms']} ms), whose ceiling is priced on PMC "
-                           "bytes that were not collected for this library build; reported instead: the longest kernel with an "
+                           "bytes that were not collected for this library build and workload; reported instead: the longest kernel with an "
                            "event-timed rate")
         top["traffic_source"] = traffic_note
         top["kernels"] = ks
@@ -424,7 +424,8 @@ def run():
                        "launch": ("hipGraph replay of the captured iteration" + (" (2 graphs, collectives eager)" if mapper is not None
                                                                                               else ""))
                        if graphed else "eager launches from Python"},
-            "roofline": roofline(prof, n, ms_step) if mapper is None else None,
+            # (ray-sharded runs: this rank's kernels on this rank's shard; the PMC bytes are collected for the N = 1 workload only)
+            "roofline": roofline(prof, n, ms_step),
             "kernel_ms": {k: round(v, 4) for k, v in sorted(prof.items())},
             "step_ms_percentiles": pct,
         }
