@@ -1,3 +1,5 @@
+"""Median eager (no hipGraph) step time of the bench workload: 7 repeats of 200 iterations after 30 warm-up steps.
+PIN=0,1 pins the process to those cores first; ESLAM_TORCH_STREAM_WAIT=1 uses torch's Stream.wait_stream for the side-stream fork / join."""
 import sys, os, time
 if os.environ.get('PIN'):
     os.sched_setaffinity(0, {int(c) for c in os.environ['PIN'].split(',')})
