@@ -198,6 +198,26 @@ __device__ __forceinline__ float jitter_one(const float* zs, int i, int S, float
     return __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), t));
 }
 
+// Counts over a NON-DECREASING array in LDS by bisection: #(a[k] <= v) and #(a[k] < v), k in [0, n).  The same numbers a
+// linear scan gives (also for NaN: 0), in <= 8 dependent reads instead of n: the rank merges below spent 56 - 96 dependent
+// LDS reads per element (in-kernel stamps: 24 k of a depth-less ray's 55 k cycles were its rank sort).
+__device__ __forceinline__ int count_le_sorted(const float* a, int n, float v) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] <= v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+__device__ __forceinline__ int count_lt_sorted(const float* a, int n, float v) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
 // one wave: the S depth-guided samples of one ray with depth d > 0 (zs: S floats of LDS owned by the wave)
 __device__ __forceinline__ void depth_guided_row(float d, int ray, int n_strat, int n_imp, float c15, float c3,
                                                  const float* __restrict__ t_free, const float* __restrict__ t_surf,
@@ -210,6 +230,9 @@ __device__ __forceinline__ void depth_guided_row(float d, int ray, int n_strat, 
     // S <= 128; larger S recomputes the other sequence's values from t_free / t_surf as before)
     const bool staged = 2 * S <= ESLAM_MAX_SAMPLES;
     float* raw = zs + S;
+    // d12 * t_free and dlo + c3 * t_surf are non-decreasing in the index when the factors are >= 0 (t_free / t_surf are
+    // ascending linspaces; rounding is monotone): then the counts below are bisections
+    const bool sorted_in = d12 >= 0.0f && c3 >= 0.0f;
     if (staged) {
         for (int i = lane; i < S; i += WAVE)
             raw[i] = (i < n_strat) ? __fadd_rn(0.0f, __fmul_rn(d12, t_free[i])) : __fadd_rn(dlo, __fmul_rn(c3, t_surf[i - n_strat]));
@@ -221,14 +244,16 @@ __device__ __forceinline__ void depth_guided_row(float d, int ray, int n_strat, 
         if (i < n_strat) {
             val = __fadd_rn(0.0f, __fmul_rn(d12, t_free[i]));
             int cnt = 0;
-            if (staged) { for (int j = 0; j < n_imp; ++j) cnt += (raw[n_strat + j] < val) ? 1 : 0; }
+            if (staged && sorted_in) cnt = count_lt_sorted(raw + n_strat, n_imp, val);
+            else if (staged) { for (int j = 0; j < n_imp; ++j) cnt += (raw[n_strat + j] < val) ? 1 : 0; }
             else { for (int j = 0; j < n_imp; ++j) cnt += (__fadd_rn(dlo, __fmul_rn(c3, t_surf[j])) < val) ? 1 : 0; }
             pos = i + cnt;
         } else {
             const int j = i - n_strat;
             val = __fadd_rn(dlo, __fmul_rn(c3, t_surf[j]));
             int cnt = 0;
-            if (staged) { for (int k = 0; k < n_strat; ++k) cnt += (raw[k] <= val) ? 1 : 0; }
+            if (staged && sorted_in) cnt = count_le_sorted(raw, n_strat, val);
+            else if (staged) { for (int k = 0; k < n_strat; ++k) cnt += (raw[k] <= val) ? 1 : 0; }
             else { for (int k = 0; k < n_strat; ++k) cnt += (__fadd_rn(0.0f, __fmul_rn(d12, t_free[k])) <= val) ? 1 : 0; }
             pos = j + cnt;
         }
@@ -365,8 +390,8 @@ __global__ __launch_bounds__(256, 2) void importance_z_kernel(const PlaneSet pla
     WAVE_SYNC();
     for (int i = lane; i < n_imp; i += WAVE) {
         const float u = u_rand ? u_rand[(int64_t)ray * n_imp + i] : rng_uniform(rng, 2u, (uint32_t)(ray * n_imp + i));
-        int inds = 0;                       // searchsorted(cdf, u, right=True): #entries <= u
-        for (int k = 0; k < nb; ++k) inds += (wt[k] <= u) ? 1 : 0;
+        // searchsorted(cdf, u, right=True): #entries <= u; the cdf is a cumsum of weights >= 0 (alpha in [0,1]): non-decreasing
+        const int inds = count_le_sorted(wt, nb, u);
         const int below = max(inds - 1, 0);
         const int above = min(nb - 1, inds);
         const float c0v = wt[below], c1v = wt[above];
@@ -381,12 +406,30 @@ __global__ __launch_bounds__(256, 2) void importance_z_kernel(const PlaneSet pla
 
     // Renderer.py:133: sort(cat(z_uni, z_samples)) as a stable rank sort (values are what matter)
     float* out_row = z_vals + (int64_t)ray * S;
+    // zu (the jittered stratified samples) is non-decreasing for an ordinary ray: an element's rank is then a bisection in zu
+    // plus a scan of the n_imp importance samples.  Checked, not assumed (far <= 0, or a jitter that rounds one ulp past its
+    // bin): any other ray keeps the all-pairs count, which is a permutation whatever the values are.
+    bool inversion = false;
+    for (int i = lane; i + 1 < n_strat; i += WAVE) inversion |= !(zu[i] <= zu[i + 1]);
+    const bool zu_sorted = __ballot(inversion) == 0ull;
     for (int i = lane; i < S; i += WAVE) {
         const float v = (i < n_strat) ? zu[i] : zn[i - n_strat];
         int pos = 0;
-        for (int k = 0; k < S; ++k) {
-            const float o2 = (k < n_strat) ? zu[k] : zn[k - n_strat];
-            pos += (o2 < v || (o2 == v && k < i)) ? 1 : 0;
+        if (zu_sorted) {
+            if (i < n_strat) {
+                // among zu itself: every k < i counts (smaller, or tied and earlier), no k > i does
+                pos = i;
+                for (int j = 0; j < n_imp; ++j) pos += (zn[j] < v) ? 1 : 0;        // k = n_strat + j > i: ties do not count
+            } else {
+                const int j0 = i - n_strat;
+                pos = count_le_sorted(zu, n_strat, v);     // k < i for every zu element: ties count
+                for (int j = 0; j < n_imp; ++j) pos += (zn[j] < v || (zn[j] == v && j < j0)) ? 1 : 0;
+            }
+        } else {
+            for (int k = 0; k < S; ++k) {
+                const float o2 = (k < n_strat) ? zu[k] : zn[k - n_strat];
+                pos += (o2 < v || (o2 == v && k < i)) ? 1 : 0;
+            }
         }
         out_row[pos] = v;
     }
