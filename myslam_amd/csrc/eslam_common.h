@@ -31,29 +31,49 @@ struct Bound {
 #define DEC_B3 1376
 #define DEC_LDS 1380
 
-__device__ __forceinline__ void stage_decoder_weights(float* lds, const eslam_decoders_t& dec, int tid, int nthreads) {
-    for (int d = 0; d < 2; ++d) {
-        const float* w1 = d ? dec.cw1 : dec.w1;
-        const float* b1 = d ? dec.cb1 : dec.b1;
-        const float* w2 = d ? dec.cw2 : dec.w2;
-        const float* b2 = d ? dec.cb2 : dec.b2;
-        const float* w3 = d ? dec.cw3 : dec.w3;
-        const float* b3 = d ? dec.cb3 : dec.b3;
-        const int nout = d ? 3 : 1;
-        float* L = lds + d * DEC_LDS;
-        for (int i = tid; i < 1024; i += nthreads) L[DEC_W1 + i] = w1[i];
-        for (int i = tid; i < 256; i += nthreads) L[DEC_W2 + i] = w2[i];
-        for (int i = tid; i < 16; i += nthreads) {
-            L[DEC_B1 + i] = b1[i];
-            L[DEC_B2 + i] = b2[i];
-        }
-        for (int i = tid; i < 64; i += nthreads) L[DEC_W3 + i] = (i < nout * 16) ? w3[i] : 0.0f;
-        for (int i = tid; i < 4; i += nthreads) L[DEC_B3 + i] = (i < nout) ? b3[i] : 0.0f;
-    }
+// One decoder's 1364 parameters into its LDS image, by 256 threads: all of a thread's loads are issued before its first LDS
+// store (4 + 1 + 1 independent loads).  The first version copied array after array - twelve load -> store loops, each
+// exposing a full L2 round trip: 12 k of a forward wave's 88 k cycles (in-kernel stamps), in every workgroup of every kernel
+// that decodes.
+struct DecStage { float a[4], b, c; int dst; };
+__device__ __forceinline__ DecStage stage_load_256(const eslam_decoders_t& dec, int d, int tid) {
+    const float* w1 = d ? dec.cw1 : dec.w1;
+    const float* b1 = d ? dec.cb1 : dec.b1;
+    const float* w2 = d ? dec.cw2 : dec.w2;
+    const float* b2 = d ? dec.cb2 : dec.b2;
+    const float* w3 = d ? dec.cw3 : dec.w3;
+    const float* b3 = d ? dec.cb3 : dec.b3;
+    const int nout = d ? 3 : 1;
+    DecStage s;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s.a[k] = w1[tid + 256 * k];
+    s.b = w2[tid];
+    // the small arrays, one element per thread: [0,16) b1, [16,32) b2, [32,96) W3 padded to 4 rows, [96,100) b3 padded
+    s.c = 0.0f;
+    s.dst = -1;
+    if (tid < 16) { s.c = b1[tid]; s.dst = DEC_B1 + tid; }
+    else if (tid < 32) { s.c = b2[tid - 16]; s.dst = DEC_B2 + tid - 16; }
+    else if (tid < 96) { if (tid - 32 < nout * 16) s.c = w3[tid - 32]; s.dst = DEC_W3 + tid - 32; }
+    else if (tid < 100) { if (tid - 96 < nout) s.c = b3[tid - 96]; s.dst = DEC_B3 + tid - 96; }
+    return s;
+}
+__device__ __forceinline__ void stage_store_256(float* L, const DecStage& s, int tid) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) L[DEC_W1 + tid + 256 * k] = s.a[k];
+    L[DEC_W2 + tid] = s.b;
+    if (s.dst >= 0) L[s.dst] = s.c;
+}
+__device__ __forceinline__ void stage_decoder_weights_256(float* L, const eslam_decoders_t& dec, int d, int tid) {
+    const DecStage s = stage_load_256(dec, d, tid);
+    stage_store_256(L, s, tid);
 }
 
 // one decoder only (the importance sampler needs the SDF decoder alone), at lds[0 .. DEC_LDS)
 __device__ __forceinline__ void stage_decoder_weights_one(float* L, const eslam_decoders_t& dec, int d, int tid, int nthreads) {
+    if (nthreads == 256) {
+        stage_decoder_weights_256(L, dec, d, tid);
+        return;
+    }
     const float* w1 = d ? dec.cw1 : dec.w1;
     const float* b1 = d ? dec.cb1 : dec.b1;
     const float* w2 = d ? dec.cw2 : dec.w2;
@@ -69,6 +89,18 @@ __device__ __forceinline__ void stage_decoder_weights_one(float* L, const eslam_
     }
     for (int i = tid; i < 64; i += nthreads) L[DEC_W3 + i] = (i < nout * 16) ? w3[i] : 0.0f;
     for (int i = tid; i < 4; i += nthreads) L[DEC_B3 + i] = (i < nout) ? b3[i] : 0.0f;
+}
+
+// both decoders: image of decoder d at lds + d * DEC_LDS
+__device__ __forceinline__ void stage_decoder_weights(float* lds, const eslam_decoders_t& dec, int tid, int nthreads) {
+    if (nthreads == 256) {       // both decoders' loads in flight together
+        const DecStage s0 = stage_load_256(dec, 0, tid), s1 = stage_load_256(dec, 1, tid);
+        stage_store_256(lds, s0, tid);
+        stage_store_256(lds + DEC_LDS, s1, tid);
+        return;
+    }
+    stage_decoder_weights_one(lds, dec, 0, tid, nthreads);
+    stage_decoder_weights_one(lds + DEC_LDS, dec, 1, tid, nthreads);
 }
 
 // normalize_3d_coordinate (reference src/common.py:215-217), same operation order.
