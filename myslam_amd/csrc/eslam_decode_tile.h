@@ -326,6 +326,24 @@ __device__ __forceinline__ short* lp_weights(float* lds, int d) { return (short*
 __device__ __forceinline__ float* lp_biases(float* lds, int d) { return lds + LP_SHORTS + d * LP_BIAS_FLOATS; }
 
 __device__ __forceinline__ void stage_decoder_weights_lowp(float* lds, const eslam_decoders_t& dec, int tid, int nthreads) {
+    if (nthreads == 256) {       // every load of the thread (both decoders) in flight before the first LDS store, as stage_load_256
+        const DecStage s0 = stage_load_256(dec, 0, tid), s1 = stage_load_256(dec, 1, tid);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const DecStage& s = d ? s1 : s0;
+            short* W = lp_weights(lds, d);
+            float* B = lp_biases(lds, d);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) W[LP_W1 + tid + 256 * k] = f2bf(s.a[k]);
+            W[LP_W2 + tid] = f2bf(s.b);
+            // stage_load_256's small-array slots: [0,16) b1, [16,32) b2, [32,96) W3 padded, [96,100) b3 padded
+            if (tid < 16) B[tid] = s.c;
+            else if (tid < 32) B[tid] = s.c;                       // B[16 + (tid - 16)]
+            else if (tid < 96) W[LP_W3 + tid - 32] = f2bf(s.c);
+            else if (tid < 100) B[32 + tid - 96] = s.c;
+        }
+        return;
+    }
     for (int d = 0; d < 2; ++d) {
         const float* w1 = d ? dec.cw1 : dec.w1;
         const float* b1 = d ? dec.cb1 : dec.b1;
