@@ -67,9 +67,12 @@ __global__ __launch_bounds__(256, FWD_WAVES) void render_fwd_kernel(const PlaneS
     // block is taken exactly once, surplus blocks exit.
     const int cpx = gridDim.x >> 3;
     const int lblock = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
-    const int slot = lblock * 4 + wave;
-    if (!LOSS && slot >= R) return;
-    if (slot < R) {                        // (LOSS: idle waves still take part in the workgroup's reduction below)
+    if (!LOSS && lblock * 4 + wave >= R) return;
+    // Persistent over the rays when the batch has more workgroups' worth of rays than the chip holds at once (the host caps the
+    // grid at FWD_WAVES workgroups per CU): the decoder weights are staged once per resident workgroup instead of once per
+    // four rays.  Round k gives every XCD the next contiguous run of the ray order.
+    // (LOSS: idle waves still take part in the workgroup's reduction below)
+    for (int slot = lblock * 4 + wave; slot < R; slot += (int)gridDim.x * 4) {
     const int ray = perm ? perm[slot] : slot;
     const float gtd = LOSS ? li.gt_depth[ray] : 0.0f;
     const bool in_batch = LOSS ? (li.ray_mask ? li.ray_mask[ray] != 0 : true) : false;
@@ -329,7 +332,18 @@ static int render_fwd_common(const char* who, const eslam_plane_t* planes, const
     const bool cl = eslam_planes_channels_last(planes, 0, NPL);
     const bool save = feat != nullptr;
     const int nblocks = (R + 3) / 4;
-    dim3 grid(((nblocks + 7) / 8) * 8), block(256);
+    static const int resident = [] {        // workgroups the chip holds at once: FWD_WAVES waves per SIMD = FWD_WAVES workgroups per CU
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        static const char* e = getenv("ESLAM_FWD_PERSIST");
+        return (e && e[0] == '0') ? (1 << 30) : ((FWD_WAVES * cus) / 8) * 8;
+    }();
+    // persistent only when the rays divide evenly over the resident workgroups (4096, 8192 rays ...): a static assignment of
+    // 2.44 rays per wave (5000 rays) runs three rounds where the hardware's own dispatch of 1250 workgroups needs 2.5
+    // (forward 95 -> 108 us at 5000 x 56)
+    int nwg = ((nblocks + 7) / 8) * 8;
+    if (nwg > resident && nwg % resident == 0) nwg = resident;
+    dim3 grid(nwg), block(256);
     hipStream_t st = (hipStream_t)stream;
     const LossIn none = {};
 #define LAUNCH(CLv, SV, LS)                                                                                             \
