@@ -617,12 +617,12 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
         }
     };
 
-    struct Rec { unsigned xy; int row; unsigned long long fresh, adjacent; };
+    struct Rec { unsigned xy; int row; unsigned long long fresh, adjacent; };     // row: BYTE offset of the g_feat row (row * 512)
     auto fetch = [&](int blk, unsigned prev_last) {
         Rec r;
         const int e = e0 + blk * WAVE + lane;
         r.xy = sxy[e];
-        r.row = sgrow[e];
+        r.row = sgrow[e] * 512;
         unsigned prev = __shfl_up(r.xy, 1, WAVE);
         if (lane == 0) prev = prev_last;
         const bool fresh = r.xy != prev;
@@ -635,17 +635,23 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
 #define WALK_N 8                   // entries per load-ahead group (2 groups in flight: 2*WALK_N VGPRs)
 #endif
     const float2_t* const wlane = (const float2_t*)sw + hx;                    // + 2 * entry
+    // A row load is TWO instructions: v_readlane of the row's byte offset into an SGPR, and a buffer load that adds that SGPR
+    // (soffset) and the lane's channel offset (voffset) to the descriptor's base - the global_load form needed a VALU add
+    // per entry in between, and the walk is bound by instruction issue.
+    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc((void*)gcol, 0, (int)((unsigned)npts * 512u - (unsigned)(d * 64 + lvl * 32) * 4u), 0x00020000);
+    const int cvoff = c * 4;
 #define LOAD_HALF(buf, rec, half)                                                             \
     _Pragma("unroll") for (int t = 0; t < WALK_N; ++t) {                                      \
-        const unsigned row = (unsigned)__builtin_amdgcn_readlane((rec).row, (half) * WALK_N + t); \
-        buf[t] = (dbg_mode >= 3) ? __uint_as_float(row) : *(const float*)(gcol + (row * 512u + (unsigned)c * 4u)); \
+        const int rowb = __builtin_amdgcn_readlane((rec).row, (half) * WALK_N + t);           \
+        buf[t] = (dbg_mode >= 3) ? __int_as_float(rowb)                                       \
+                                 : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grsrc, cvoff, rowb, 0)); \
     }
 #define WALK_HALF(buf, rec, half, ebase)                                                      \
     _Pragma("unroll") for (int t = 0; t < WALK_N; ++t) {                                      \
         const int idx = (half) * WALK_N + t;                                                  \
         const float2_t w2 = (dbg_mode == 4) ? (float2_t){1.f, 2.f} : wlane[2 * ((ebase) + idx)]; \
-        if (((rec).fresh >> idx) & 1ull) {                                                    \
-            if (((rec).adjacent >> idx) & 1ull) {                                             \
+        if (((idx < 32 ? fresh_lo : fresh_hi) >> (idx & 31)) & 1u) {     /* one s_bitcmp on a 32-bit scalar */ \
+            if (((idx < 32 ? adj_lo : adj_hi) >> (idx & 31)) & 1u) {                          \
                 /* next cell along the minor axis: its first texel column is our second one - keep those sums */ \
                 flush(true);                                                                  \
                 const acc_t s0 = __shfl_xor(acc0, 32, WAVE), s1 = __shfl_xor(acc1, 32, WAVE); \
@@ -680,6 +686,10 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
         Rec nxt = rec;
         if (blk + 1 < nblk) nxt = fetch(blk + 1, last_xy);
         const int ebase = e0 + blk * WAVE;
+        const unsigned fresh_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rec.fresh);
+        const unsigned fresh_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rec.fresh >> 32));
+        const unsigned adj_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rec.adjacent);
+        const unsigned adj_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(rec.adjacent >> 32));
 #pragma unroll
         for (int g2 = 0; g2 < ngrp; g2 += 2) {
             LOAD_HALF(gb, rec, g2 + 1)
