@@ -339,6 +339,11 @@ int eslam_deterministic(void);
  * far - the fork / join of the side stream the ray ordering (eslam_ray_order, what the backward's scatter bundles by) runs
  * on beside the samplers and the forward kernel.  One hipEventRecord + hipStreamWaitEvent; valid inside a stream capture. */
 int eslam_stream_wait(eslam_stream_t waiter, eslam_stream_t signaler);
+
+/* Host-side helper: zero `bytes` bytes at `ptr` on `stream`.  The gradient buffer autograd hands to the optimiser has to be
+ * zero before the scatter adds into it (the reference's `fill_` of the plane gradients is 15.9 % of its CPU step, SURVEY.md
+ * section 8a6); cleared at the head of the side stream it runs beside the samplers. */
+int eslam_zero_async(void* ptr, int64_t bytes, eslam_stream_t stream);
 int64_t eslam_loss_scratch_floats(int64_t n_rays);
 int eslam_loss_scratch_reset(float* scratch, int64_t floats, eslam_stream_t stream);
 int eslam_loss_value(const float* depth, const float* rgb, const float* sdf, const float* z_vals,

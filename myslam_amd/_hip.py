@@ -57,6 +57,7 @@ SIGNATURES = {
     "eslam_render_fwd_lowp": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "eslam_ray_order": (_i, [_vp, _vp, _i, _vp, _vp]),
     "eslam_stream_wait": (_i, [_vp, _vp]),
+    "eslam_zero_async": (_i, [_vp, _i64, _vp]),
     "eslam_bwd_workspace_bytes": (_i64, [_i64]),
     "eslam_render_bwd": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                               _vp, _vp, _vp, _vp]),

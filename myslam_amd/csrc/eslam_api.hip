@@ -198,3 +198,20 @@ extern "C" int eslam_stream_wait(eslam_stream_t waiter, eslam_stream_t signaler)
     }
     return 0;
 }
+
+
+// Zero `bytes` bytes at `ptr` on `stream` (hipMemsetAsync): the Python layer clears the plane-gradient buffer of an
+// iteration at the head of the ray-order side stream, beside the samplers (latency-bound kernels that move almost no
+// bytes), instead of in front of the backward pass.
+extern "C" int eslam_zero_async(void* ptr, int64_t bytes, eslam_stream_t stream) {
+    if (bytes <= 0) return 0;
+    if (!ptr) {
+        eslam_set_error("eslam_zero_async: null pointer");
+        return 1;
+    }
+    if (hipMemsetAsync(ptr, 0, (size_t)bytes, (hipStream_t)stream) != hipSuccess) {
+        eslam_set_error("eslam_zero_async: %s", hipGetErrorString(hipGetLastError()));
+        return 2;
+    }
+    return 0;
+}

@@ -92,9 +92,9 @@ class grad_sink:
 _grad_layout_cache = {}
 
 
-def _alloc_plane_grads(planes):
+def _alloc_plane_grads(planes, zero=True):
     """One flat zero buffer, 12 views with the planes' own strides (so autograd can adopt them without a copy
-    and a multi-GPU caller can all-reduce the flat buffer)."""
+    and a multi-GPU caller can all-reduce the flat buffer).  zero=False: uninitialised (the caller clears it)."""
     key = tuple((tuple(p.shape), p.stride()) for p in planes)
     layout = _grad_layout_cache.get(key)
     if layout is None:
@@ -106,7 +106,7 @@ def _alloc_plane_grads(planes):
             off += p.numel()
         layout = _grad_layout_cache[key] = (layout, off)
     entries, total = layout
-    flat = torch.zeros(total, device=planes[0].device, dtype=torch.float32)
+    flat = (torch.zeros if zero else torch.empty)(total, device=planes[0].device, dtype=torch.float32)
     return flat, [torch.as_strided(flat, shp, st, off) for shp, st, off in entries]
 
 
@@ -124,9 +124,16 @@ _dec_param_cache = {}
 _side_streams = {}
 
 
-def ray_order_async(rays_o, rays_d):
+# ESLAM_PRECLEAR=0: the plane-gradient buffer is a torch.zeros in the backward pass instead of a memset on the side stream
+_PRECLEAR = os.environ.get("ESLAM_PRECLEAR", "1") == "1"
+
+
+def ray_order_async(rays_o, rays_d, grad_planes=None):
     """Launch eslam_ray_order on a side stream (it depends only on the rays, so it overlaps the samplers).
-    Returns (perm int32 [R], stream to join before the order is used)."""
+    Returns (perm int32 [R], stream to join before the order is used[, gradient views]).
+    grad_planes: the 12 planes when the coming backward pass will need their gradient buffer: it is allocated here and
+    cleared at the HEAD of the side stream, beside the samplers (27 - 70 MB: 6 - 15 us in front of the backward pass
+    otherwise; beside the forward kernel the memset's writes slowed the forward down by more than that)."""
     _hip.require_gpu_f32("rays_o", rays_o)
     _hip.require_gpu_f32("rays_d", rays_d)
     dev = rays_o.device
@@ -136,15 +143,21 @@ def ray_order_async(rays_o, rays_d):
     if side is None:
         side = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
     perm = torch.empty(R, dtype=torch.int32, device=dev)
-    _hip.stream_wait(dev, side, None)           # the rays come from work on the caller's stream
+    pre = None
+    if grad_planes is not None and _PRECLEAR and _grad_sink is None:
+        pre = _alloc_plane_grads(grad_planes, zero=False)      # on the caller's stream: its allocator's memory
+    _hip.stream_wait(dev, side, None)           # the rays - and any earlier use of that memory - come from work on the caller's stream
     with _hip.on_device(dev):
+        if pre is not None:
+            _hip.check(_hip.lib().eslam_zero_async(_hip.ptr(pre[0]), pre[0].numel() * 4, ctypes.c_void_p(side.cuda_stream)),
+                       "eslam_zero_async")
         _hip.check(_hip.lib().eslam_ray_order(_hip.ptr(ro), _hip.ptr(rd), R, _hip.ptr(perm),
                                               ctypes.c_void_p(side.cuda_stream)), "eslam_ray_order")
     perm.record_stream(side)
     for t, src in ((ro, rays_o), (rd, rays_d)):
         if t.data_ptr() != src.data_ptr():
             t.record_stream(side)        # a contiguous copy made on the current stream and read on the side stream
-    return perm, side
+    return (perm, side) if pre is None else (perm, side, pre[1])
 
 
 # The forward kernel can process rays in the bundling order of the backward (ESLAM_FWD_ORDER=1).  Off: measured on
@@ -292,8 +305,11 @@ class RenderFn(torch.autograd.Function):
         # saved features: float32, or (mixed precision) the bf16 values the decoders consumed - half the bytes
         feat = torch.empty(R * S, 128, device=dev, dtype=torch.float32 if half is None else torch.bfloat16) if needs else None
         order = None
+        ctx.pregrads = None
         if order_in is not None:
-            order, side = order_in
+            order, side = order_in[0], order_in[1]
+            if len(order_in) > 2 and needs:
+                ctx.pregrads = order_in[2]          # cleared on the side stream (ray_order_async), joined below
             if _FWD_USES_ORDER:
                 _hip.stream_wait(dev, None, side)
                 side = None
@@ -378,7 +394,10 @@ class RenderFn(torch.autograd.Function):
             sink.zero_()
             grads = sink.views[:12]
         elif need_planes:
-            _, grads = _alloc_plane_grads(planes)
+            grads = getattr(ctx, "pregrads", None)
+            ctx.pregrads = None
+            if grads is None:
+                _, grads = _alloc_plane_grads(planes)
         arr, _ = _hip.make_planes(_split_planes([p.detach() for p in planes]), grads, half=ctx.half)
         dec, keep = _hip.make_decoders([p.detach() for p in params], beta.detach())
         if sink is not None:

@@ -37,7 +37,8 @@ class Renderer(object):
         wants_grad = torch.is_grad_enabled() and (rays_o.requires_grad or rays_d.requires_grad or
                                                   any(p.requires_grad for p in flat_planes) or
                                                   any(p.requires_grad for p in decoders.parameters()))
-        order = ops.ray_order_async(rays_o, rays_d) if wants_grad else None
+        planes_grad = torch.is_grad_enabled() and any(p.requires_grad for p in flat_planes)
+        order = ops.ray_order_async(rays_o, rays_d, flat_planes if planes_grad else None) if wants_grad else None
         z_vals = ops.sample_z(rays_o, rays_d, gt_depth, all_planes, decoders, self._bound6, truncation,
                               self.n_stratified, self.n_importance, self.perturb, _rand)
         beta = ops.beta_tensor(decoders.beta, rays_o.device)
