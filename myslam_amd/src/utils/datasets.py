@@ -1,10 +1,11 @@
 """RGB-D sequence readers: same classes, constructor arguments and items as reference src/utils/datasets.py:54-263
-(`get_dataset`, `BaseDataset`, `Replica`, `ScanNet`, `TUM_RGBD`), with PIL + numpy + torch instead of OpenCV (cv2 is not
+(`get_dataset`, `SeqSampler`, `BaseDataset`, `Replica`, `ScanNet`, `TUM_RGBD`; `readEXR_onlydepth` is named but
+not built: no OpenEXR here and no shipped configuration uses it), with PIL + numpy + torch instead of OpenCV (cv2 is not
 available in this image).  Host code: the callers either side of the hot path need it to
 feed real sequences to the tracking / mapping loops; nothing here touches the GPU kernels.
 
 Item: `(index, color [H',W',3] float RGB in [0,1], depth [H',W'] float32 metres * scale, c2w [4,4] float32)` after the
-optional resize to `crop_size` and the `crop_edge` crop, exactly as datasets.py:88-114.
+optional resize to `crop_size` and the `crop_edge` crop (datasets.py:88-114).
 
 What is bit-for-bit the reference's arithmetic: 16-bit PNG depth / png_depth_scale * scale, the crop_size resize (the same
 F.interpolate calls), the edge crop, trajectory parsing, the OpenGL flip `c2w[:3, 1:3] *= -1`, TUM's timestamp association
@@ -69,96 +70,160 @@ def undistort(color, K, dist):
 
 
 def get_dataset(cfg, args, scale, device='cuda:0'):
-    return dataset_dict[cfg['dataset']](cfg, args, scale, device=device)
+    """The reader class registered for cfg['dataset'] (datasets.py:51-52)."""
+    try:
+        reader = dataset_dict[cfg['dataset']]
+    except KeyError:
+        raise KeyError(f"unknown dataset {cfg['dataset']!r}; known: {sorted(dataset_dict)}") from None
+    return reader(cfg, args, scale, device=device)
+
+
+class SeqSampler(torch.utils.data.Sampler):
+    """Indices 0, step, 2*step, ... of a sequence of n_samples frames, plus the last frame when include_last
+    (the mapper's frame reader walks the sequence with it; datasets.py:33-48, Mapper.py:102)."""
+
+    def __init__(self, n_samples, step, include_last=True):
+        self.n_samples, self.step, self.include_last = int(n_samples), int(step), bool(include_last)
+
+    def _indices(self):
+        idx = list(range(0, self.n_samples, self.step))
+        if self.include_last and self.n_samples > 0 and idx[-1] != self.n_samples - 1:
+            idx.append(self.n_samples - 1)
+        return idx
+
+    def __iter__(self):
+        return iter(self._indices())
+
+    def __len__(self):
+        return len(self._indices())
+
+
+def readEXR_onlydepth(filename):
+    """datasets.py:14-31 reads the Z channel of an OpenEXR file.  No dataset the reference ships a config for stores depth
+    that way (Replica, ScanNet and TUM are 16-bit PNG) and the OpenEXR bindings are not in this image: named so that
+    `from src.utils.datasets import readEXR_onlydepth` resolves, raising at call time."""
+    raise ImportError("readEXR_onlydepth needs the OpenEXR Python bindings, which this build does not depend on; "
+                      "the PNG readers cover Replica, ScanNet and TUM RGB-D")
+
+
+# ---- the per-frame pipeline, one small function per step; BaseDataset.__getitem__ strings them together ----------------
+def _load_rgbd(color_path, depth_path, png_depth_scale, K_dist=None):
+    """Files -> colour [Hc,Wc,3] float64 in [0,1] (RGB) and depth [Hd,Wd] float32 in metres.  Lens distortion (TUM) is
+    removed from the colour image only: the depth maps are registered to the undistorted view already."""
+    rgb = _imread_color(color_path)
+    if K_dist is not None:
+        rgb = undistort(rgb, *K_dist)
+    metres = _imread_depth(depth_path).astype(np.float32) / png_depth_scale
+    return torch.from_numpy(rgb / 255.), torch.from_numpy(metres)
+
+
+def _match_size(color, hw):
+    """Colour image brought to the depth image's size (ScanNet ships 1296x968 colour beside 640x480 depth): bilinear on
+    pixel centres, which is what cv2.resize's default does."""
+    if tuple(color.shape[:2]) == tuple(hw):
+        return color
+    chw = color.permute(2, 0, 1)[None]
+    return F.interpolate(chw, tuple(hw), mode='bilinear', align_corners=False)[0].permute(1, 2, 0).contiguous()
+
+
+def _resize_pair(color, depth, size):
+    """cfg cam.crop_size is a RESIZE of both images to (H', W'), intrinsics being rescaled by the caller (ESLAM.update_cam):
+    colour bilinear with aligned corners, depth nearest (no mixing of depths across an edge)."""
+    if size is None:
+        return color, depth
+    c = F.interpolate(color.permute(2, 0, 1)[None], size, mode='bilinear', align_corners=True)[0]
+    d = F.interpolate(depth[None, None], size, mode='nearest')[0, 0]
+    return c.permute(1, 2, 0).contiguous(), d
+
+
+def _trim(color, depth, edge):
+    """cfg cam.crop_edge: drop `edge` pixels on every side (the rim of ScanNet / TUM colour images is invalid)."""
+    if edge <= 0:
+        return color, depth
+    return color[edge:-edge, edge:-edge], depth[edge:-edge, edge:-edge]
+
+
+def _cam_key(cam, key, default=None):
+    return cam[key] if key in cam else default
 
 
 class BaseDataset(Dataset):
+    """What the three readers share: camera / scale bookkeeping and the frame pipeline.  A subclass provides
+    `color_paths`, `depth_paths`, `poses` (list of [4,4] float32 c2w in the renderer's convention) and `n_img`."""
+
     def __init__(self, cfg, args, scale, device='cuda:0'):
-        super(BaseDataset, self).__init__()
-        self.name = cfg['dataset']
-        self.device = device
-        self.scale = scale
-        self.png_depth_scale = cfg['cam']['png_depth_scale']
-        self.H, self.W, self.fx, self.fy, self.cx, self.cy = (cfg['cam'][k] for k in ('H', 'W', 'fx', 'fy', 'cx', 'cy'))
-        self.distortion = np.array(cfg['cam']['distortion']) if 'distortion' in cfg['cam'] else None
-        self.crop_size = cfg['cam']['crop_size'] if 'crop_size' in cfg['cam'] else None
-        self.input_folder = cfg['data']['input_folder'] if getattr(args, 'input_folder', None) is None else args.input_folder
-        self.crop_edge = cfg['cam']['crop_edge']
+        super().__init__()
+        cam = cfg['cam']
+        self.name, self.device, self.scale = cfg['dataset'], device, scale
+        for key in ('H', 'W', 'fx', 'fy', 'cx', 'cy', 'png_depth_scale', 'crop_edge'):
+            setattr(self, key, cam[key])
+        dist = _cam_key(cam, 'distortion')
+        self.distortion = None if dist is None else np.array(dist)
+        self.crop_size = _cam_key(cam, 'crop_size')
+        override = getattr(args, 'input_folder', None)
+        self.input_folder = cfg['data']['input_folder'] if override is None else override
 
     def __len__(self):
         return self.n_img
 
     def __getitem__(self, index):
-        color_data = _imread_color(self.color_paths[index])
-        depth_data = _imread_depth(self.depth_paths[index])
+        K_dist = None
         if self.distortion is not None:
-            # undistortion is only applied on the colour image, not on depth (datasets.py:93-96)
-            color_data = undistort(color_data, as_intrinsics_matrix([self.fx, self.fy, self.cx, self.cy]), self.distortion)
-        color_data = color_data / 255.                                   # float64, as in the reference
-        depth_data = depth_data.astype(np.float32) / self.png_depth_scale
-        H, W = depth_data.shape
-        color_data = torch.from_numpy(color_data)
-        if tuple(color_data.shape[:2]) != (H, W):                        # cv2.resize(color, (W, H)), datasets.py:102
-            color_data = F.interpolate(color_data.permute(2, 0, 1)[None], (H, W), mode='bilinear',
-                                       align_corners=False)[0].permute(1, 2, 0).contiguous()
-        depth_data = torch.from_numpy(depth_data) * self.scale
-
-        if self.crop_size is not None:
-            # follow the pre-processing step in lietorch, actually is resize (datasets.py:106-113)
-            color_data = color_data.permute(2, 0, 1)
-            color_data = F.interpolate(color_data[None], self.crop_size, mode='bilinear', align_corners=True)[0]
-            depth_data = F.interpolate(depth_data[None, None], self.crop_size, mode='nearest')[0, 0]
-            color_data = color_data.permute(1, 2, 0).contiguous()
-
-        edge = self.crop_edge
-        if edge > 0:
-            # crop image edge, there are invalid values on the edge of the colour image
-            color_data = color_data[edge:-edge, edge:-edge]
-            depth_data = depth_data[edge:-edge, edge:-edge]
-        pose = self.poses[index]
-        pose[:3, 3] *= self.scale          # (in place, as the reference does: reading an item twice scales twice when scale != 1)
-        return index, color_data, depth_data, pose
+            K_dist = (as_intrinsics_matrix([self.fx, self.fy, self.cx, self.cy]), self.distortion)
+        color, depth = _load_rgbd(self.color_paths[index], self.depth_paths[index], self.png_depth_scale, K_dist)
+        color = _match_size(color, depth.shape)
+        color, depth = _resize_pair(color, depth * self.scale, self.crop_size)
+        color, depth = _trim(color, depth, self.crop_edge)
+        # the stored pose itself is scaled, in place, as the reference does it: an item read twice is scaled twice when
+        # scale != 1 (every config of the reference has scale 1)
+        c2w = self.poses[index]
+        c2w[:3, 3] *= self.scale
+        return index, color, depth, c2w
 
 
-def _flip_yz(c2w):
-    """The datasets' camera looks along +z with y down; the renderer's looks along -z with y up (datasets.py:132-133)."""
-    c2w[:3, 1] *= -1
-    c2w[:3, 2] *= -1
-    return torch.from_numpy(c2w).float()
+def _to_renderer_frame(mats):
+    """[n,4,4] float64 dataset poses (camera looks along +z, y down) -> list of float32 tensors in the renderer's OpenGL
+    convention (looks along -z, y up): the y and z columns of the rotation change sign, the translation does not."""
+    out = np.array(mats, dtype=np.float64, copy=True).reshape(-1, 4, 4)
+    out[:, :3, 1:3] *= -1.0
+    return [torch.from_numpy(m).float() for m in out]
+
+
+def _frame_number(path):
+    return int(os.path.splitext(os.path.basename(path))[0])
 
 
 class Replica(BaseDataset):
+    """<folder>/results/frameNNNNNN.jpg + depthNNNNNN.png, <folder>/traj.txt: one row-major 4x4 c2w per line."""
+
     def __init__(self, cfg, args, scale, device='cuda:0'):
-        super(Replica, self).__init__(cfg, args, scale, device)
-        self.color_paths = sorted(glob.glob(f'{self.input_folder}/results/frame*.jpg'))
-        self.depth_paths = sorted(glob.glob(f'{self.input_folder}/results/depth*.png'))
+        super().__init__(cfg, args, scale, device)
+        frames = os.path.join(self.input_folder, 'results')
+        self.color_paths = sorted(glob.glob(os.path.join(frames, 'frame*.jpg')))
+        self.depth_paths = sorted(glob.glob(os.path.join(frames, 'depth*.png')))
         self.n_img = len(self.color_paths)
-        self.load_poses(f'{self.input_folder}/traj.txt')
+        self.load_poses(os.path.join(self.input_folder, 'traj.txt'))
 
     def load_poses(self, path):
-        self.poses = []
-        with open(path, "r") as f:
-            lines = f.readlines()
-        for i in range(self.n_img):
-            self.poses.append(_flip_yz(np.array(list(map(float, lines[i].split()))).reshape(4, 4)))
+        # the file may hold more lines than there are frames on disk: only the first n_img are used
+        table = np.loadtxt(path, dtype=np.float64, ndmin=2, max_rows=self.n_img if self.n_img else None)
+        self.poses = _to_renderer_frame(table[:self.n_img].reshape(-1, 4, 4))
 
 
 class ScanNet(BaseDataset):
+    """<folder>/color/<k>.jpg, depth/<k>.png, pose/<k>.txt (4 lines of 4 numbers); k is a plain integer, so the files are
+    ordered numerically, not lexicographically."""
+
     def __init__(self, cfg, args, scale, device='cuda:0'):
-        super(ScanNet, self).__init__(cfg, args, scale, device)
-        number = lambda x: int(os.path.basename(x)[:-4])
-        self.color_paths = sorted(glob.glob(os.path.join(self.input_folder, 'color', '*.jpg')), key=number)
-        self.depth_paths = sorted(glob.glob(os.path.join(self.input_folder, 'depth', '*.png')), key=number)
+        super().__init__(cfg, args, scale, device)
+        listing = lambda sub, ext: sorted(glob.glob(os.path.join(self.input_folder, sub, '*' + ext)), key=_frame_number)
+        self.color_paths, self.depth_paths = listing('color', '.jpg'), listing('depth', '.png')
         self.load_poses(os.path.join(self.input_folder, 'pose'))
         self.n_img = len(self.color_paths)
 
     def load_poses(self, path):
-        self.poses = []
-        pose_paths = sorted(glob.glob(os.path.join(path, '*.txt')), key=lambda x: int(os.path.basename(x)[:-4]))
-        for pose_path in pose_paths:
-            with open(pose_path, "r") as f:
-                ls = [list(map(float, line.split(' '))) for line in f.readlines()]
-            self.poses.append(_flip_yz(np.array(ls).reshape(4, 4)))
+        files = sorted(glob.glob(os.path.join(path, '*.txt')), key=_frame_number)
+        self.poses = _to_renderer_frame([np.loadtxt(f, dtype=np.float64) for f in files]) if files else []
 
 
 class TUM_RGBD(BaseDataset):
@@ -193,13 +258,19 @@ class TUM_RGBD(BaseDataset):
         return [tuple(int(c[n]) for c in cols) for n in np.flatnonzero(keep)]
 
     @staticmethod
-    def pose_matrix_from_quaternion(pvec):
-        """(tx, ty, tz, qx, qy, qz, qw) -> 4x4 camera-to-world matrix."""
+    def pose_matrices(vecs):
+        """[n,7] rows (tx, ty, tz, qx, qy, qz, qw: scalar-last, the TUM file order) -> [n,4,4] camera-to-world matrices."""
         from scipy.spatial.transform import Rotation
-        pose = np.eye(4)
-        pose[:3, :3] = Rotation.from_quat(pvec[3:]).as_matrix()
-        pose[:3, 3] = pvec[:3]
-        return pose
+        vecs = np.asarray(vecs, dtype=np.float64).reshape(-1, 7)
+        mats = np.tile(np.eye(4), (vecs.shape[0], 1, 1))
+        mats[:, :3, :3] = Rotation.from_quat(vecs[:, 3:]).as_matrix()
+        mats[:, :3, 3] = vecs[:, :3]
+        return mats
+
+    @classmethod
+    def pose_matrix_from_quaternion(cls, pvec):
+        """One row of the trajectory file -> 4x4 matrix (the name the reference's callers use, datasets.py:249)."""
+        return cls.pose_matrices(pvec)[0]
 
     def loadtum(self, datapath, frame_rate=-1):
         pose_file = next((f for f in ('groundtruth.txt', 'pose.txt') if os.path.isfile(os.path.join(datapath, f))), None)
@@ -215,16 +286,14 @@ class TUM_RGBD(BaseDataset):
         for tr in triples[1:]:
             if t_rgb[tr[0]] - t_rgb[kept[-1][0]] > 1.0 / frame_rate:
                 kept.append(tr)
-        vecs = gt[:, 1:].astype(np.float64)
-        first_inv = np.linalg.inv(self.pose_matrix_from_quaternion(vecs[kept[0][2]])) if kept else None
-        images, depths, poses = [], [], []
-        for n, (i, j, k) in enumerate(kept):
-            images.append(os.path.join(datapath, rgb[i, 1]))
-            depths.append(os.path.join(datapath, dep[j, 1]))
-            # trajectory re-based on the first kept frame (whose pose becomes the identity), then the OpenGL flip
-            c2w = np.eye(4) if n == 0 else first_inv @ self.pose_matrix_from_quaternion(vecs[k])
-            poses.append(_flip_yz(c2w))
-        return images, depths, poses
+        if not kept:
+            return [], [], []
+        images = [os.path.join(datapath, rgb[i, 1]) for i, _, _ in kept]
+        depths = [os.path.join(datapath, dep[j, 1]) for _, j, _ in kept]
+        # trajectory re-based on the first kept frame (whose pose becomes exactly the identity), then the OpenGL flip
+        world = self.pose_matrices(gt[[k for _, _, k in kept], 1:].astype(np.float64))
+        rebased = np.stack([np.eye(4)] + [m for m in np.linalg.inv(world[0]) @ world[1:]])
+        return images, depths, _to_renderer_frame(rebased)
 
 
 dataset_dict = {

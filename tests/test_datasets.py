@@ -177,3 +177,18 @@ def test_tum_items_and_undistort(tmp_path):
     src_u = 20.0 * x * (1 + k1 * r2) + K[0, 2]                  # where the distorted image shows this ray
     assert abs(float(out[v, u, 0]) - 10 * src_u) <= 1.0          # the ramp is linear in u: bilinear sampling is exact to rounding
     assert out[0, 0, 0] == 0 or out.shape == img.shape          # corners map outside the image: filled with 0
+
+
+def test_seq_sampler_and_named_but_absent_exr_reader():
+    """SeqSampler (reference datasets.py:33-48; imported by the reference's Mapper from this module): every step-th index,
+    plus the last index when asked for and not already there."""
+    assert list(ds.SeqSampler(10, 4)) == [0, 4, 8, 9] and len(ds.SeqSampler(10, 4)) == 4
+    assert list(ds.SeqSampler(9, 4)) == [0, 4, 8]                       # the last index is already a multiple of the step
+    assert list(ds.SeqSampler(10, 4, include_last=False)) == [0, 4, 8]
+    assert list(ds.SeqSampler(1, 5)) == [0] and list(ds.SeqSampler(0, 5)) == []
+    loader = torch.utils.data.DataLoader(list(range(10)), batch_size=1, sampler=ds.SeqSampler(10, 3))
+    assert [int(b[0]) for b in loader] == [0, 3, 6, 9]
+    with pytest.raises(ImportError):
+        ds.readEXR_onlydepth("x.exr")
+    with pytest.raises(KeyError):
+        ds.get_dataset(dict(dataset="kitti"), ARGS, 1.0)
