@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ESLAM_ABI_VERSION 3
+#define ESLAM_ABI_VERSION 4
 #define ESLAM_C_DIM 32          /* feature channels per plane (configs/ESLAM.yaml:77)               */
 #define ESLAM_HIDDEN 16         /* decoder hidden width (src/networks/decoders.py:39)               */
 #define ESLAM_FEAT (2 * ESLAM_C_DIM)   /* coarse || fine                                          */
@@ -154,6 +154,15 @@ int eslam_render_fwd_loss(const eslam_plane_t* planes, const eslam_decoders_t* d
  * mixed-precision training loop runs after every optimiser step.                                            */
 int eslam_planes_to_half(const eslam_plane_t* planes, eslam_stream_t stream);
 
+/* Layout change of all 12 planes in one launch, for callers that keep the reference's own NCHW-contiguous planes
+ * (src/ESLAM.py:199-210: a texel's 32 channels lie h*w floats apart): field 0 copies src[i].data into the memory
+ * dst[i].data points at, field 1 copies src[i].grad into dst[i].grad.  One side of every plane must be dense
+ * NCHW-contiguous, the other dense channels-last (stride_c 1, stride_x 32, stride_y 32 w), the same way for all 12.
+ * The shipped binding runs it on the planes in front of the kernels and on the gradients behind them whenever the caller's
+ * planes are not channels-last and the batch is large enough to pay for 2 x (plane bytes) of HBM traffic; nothing is kept
+ * across calls (the mapper swaps the plane Parameters every frame, src/Mapper.py:254-266).                          */
+int eslam_planes_relayout(const eslam_plane_t* src, const eslam_plane_t* dst, int field, eslam_stream_t stream);
+
 /* Mixed-precision forward for inference (BASELINE.json configs[4], a tolerance study): planes_f16[i].data points to
  * IEEE-half data of a channels-last [1,32,h,w] plane (strides in half elements: stride_c = 1, stride_x = 32), the decoder
  * weights are rounded to bf16 inside the kernel and run on bf16 MFMA with float32 accumulation; everything after the MLPs
@@ -179,25 +188,13 @@ int64_t eslam_bwd_workspace_bytes(int64_t n_points);
  * g_beta [1] (may be NULL), and when g_rays_o / g_rays_d are
  * non-NULL overwrites them ([R,3] each) with the gradient through pts = o + d z.  z_vals carries no gradient
  * (Renderer.py builds it under no_grad / from gt_depth).  ray_order: the buffer eslam_ray_order filled, or NULL
- * (then the order is computed here).  scatter_records: from eslam_scatter_prep, or NULL (see there).
+ * (then the order is computed here).
  * workspace: eslam_bwd_workspace_bytes(R*S) bytes.                                                          */
 int eslam_render_bwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
                      const float* rays_o, const float* rays_d, const float* z_vals, int R, int S,
                      const float* sdf, const float* raw_rgb, const float* feat, const float* g_depth,
                      const float* g_rgb, const float* g_sdf, float* g_dec, float* g_beta, float* g_rays_o,
-                     float* g_rays_d, const int32_t* ray_order, const void* scatter_records, void* workspace,
-                     eslam_stream_t stream);
-
-/* The first half of the plane-gradient scatter of eslam_render_bwd, runnable before the backward pass: which texel cell of
- * each of the 12 planes every sample falls into, and each ray bundle's samples sorted by cell, depend on the sample
- * positions only - not on any gradient.  eslam_scatter_prep computes them (ray_order: from eslam_ray_order, required)
- * into records [eslam_scatter_records_bytes(R, S) bytes]; hand the buffer to eslam_render_bwd* as `scatter_records`
- * together with the same ray_order, and its scatter only loads the sorted records and walks them.  A caller can issue
- * it on a side stream right after the samplers, beside the forward kernel; NULL scatter_records = the backward does
- * both halves itself.  Planes, rays and z_vals must be the ones the backward is given.                             */
-int64_t eslam_scatter_records_bytes(int R, int S);
-int eslam_scatter_prep(const eslam_plane_t* planes, const float* bound6_host, const float* rays_o, const float* rays_d,
-                       const float* z_vals, int R, int S, const int32_t* ray_order, void* records, eslam_stream_t stream);
+                     float* g_rays_d, const int32_t* ray_order, void* workspace, eslam_stream_t stream);
 
 /* eslam_render_bwd for an iteration whose loss is the mapping loss (src/Mapper.py:110-144,337-346; with ray_mask the
  * tracker's, src/Tracker.py:114-148,197-204): the upstream gradients d loss / d (depth, rgb, sdf) are formed INSIDE the
@@ -214,7 +211,7 @@ int eslam_render_bwd_loss(const eslam_plane_t* planes, const eslam_decoders_t* d
                           const float* weights5_host, const uint8_t* ray_mask, const float* acc,
                           const float* upstream, float* loss_out, const float* g_depth, const float* g_rgb,
                           const float* g_sdf, float* g_dec, float* g_beta, float* g_rays_o, float* g_rays_d,
-                          const int32_t* ray_order, const void* scatter_records, void* workspace, eslam_stream_t stream);
+                          const int32_t* ray_order, void* workspace, eslam_stream_t stream);
 
 /* Decoder-only query.  Replaces src/networks/decoders.py:127-146 (Decoders.forward), the entry used by
  * src/utils/Mesher.py:151 on up to 500k points.  pts [N,3] world coordinates -> raw [N,4] = (r,g,b,sdf).
@@ -332,6 +329,9 @@ int eslam_keep_best(const float* loss, const float* pose, int n, float* best, fl
  * eslam_deterministic(): 1 when the process runs with ESLAM_DETERMINISTIC=1 - the loss's sums are then reduced in a fixed
  * order (per-workgroup slots instead of float atomics) and the plane-gradient scatter accumulates in 64-bit fixed point
  * (integer adds commute), so every output of the path is bitwise reproducible from run to run, at a lower speed.
+ * Range of the fixed-point sums: units of 2^-44, so one contribution must stay below 2^18 = 2.6e5 in magnitude and a texel's
+ * sum below 5.2e5; a contribution beyond the limit, or a NaN / Inf one, poisons the texel's float gradient with NaN instead
+ * of being saturated silently.  One int64 shadow of the planes per device, allocated at the first (eager) use.
  * eslam_loss_scratch_reset: back to the freshly-zeroed state, e.g. after a graph was aborted mid-flight.             */
 int eslam_deterministic(void);
 

@@ -11,10 +11,10 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# ESLAM_HIP_LIB: another build of the SAME library (A/B of compile-time kernel variants, tools/ab_variants.py); never a fallback
+# ESLAM_HIP_LIB: another build of the SAME library (A/B of compile-time kernel variants: `make variant`, tools/ab_inproc.py); never a fallback
 LIB_PATH = os.environ.get("ESLAM_HIP_LIB") or os.path.join(_HERE, "lib", "libeslam_hip.so")
 
-ABI_VERSION = 3              # ESLAM_ABI_VERSION
+ABI_VERSION = 4              # ESLAM_ABI_VERSION
 N_DEC_PARAMS = 2692
 N_PLANES = 12
 
@@ -54,17 +54,16 @@ SIGNATURES = {
     "eslam_render_fwd_loss": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _BP, _vp,
                                    _vp, _vp, _vp, _vp, _vp]),
     "eslam_planes_to_half": (_i, [_PP, _vp]),
+    "eslam_planes_relayout": (_i, [_PP, _PP, _i, _vp]),
     "eslam_render_fwd_lowp": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "eslam_ray_order": (_i, [_vp, _vp, _i, _vp, _vp]),
     "eslam_stream_wait": (_i, [_vp, _vp]),
     "eslam_zero_async": (_i, [_vp, _i64, _vp]),
     "eslam_bwd_workspace_bytes": (_i64, [_i64]),
     "eslam_render_bwd": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                              _vp, _vp, _vp, _vp]),
-    "eslam_scatter_records_bytes": (_i64, [_i, _i]),
-    "eslam_scatter_prep": (_i, [_PP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+                              _vp, _vp, _vp]),
     "eslam_render_bwd_loss": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _BP, _vp, _vp,
-                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "eslam_decode_fwd": (_i, [_PP, _DP, _BP, _vp, _i64, _i, _vp, _vp, _vp]),
     "eslam_decode_bwd": (_i, [_PP, _DP, _BP, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "eslam_mapping_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _BP, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -3,6 +3,8 @@
 #include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <atomic>
+#include <mutex>
 #include "eslam_common.h"
 
 static thread_local char g_err[512] = "";
@@ -174,24 +176,43 @@ extern "C" const char* eslam_profile_name(int kernel_id) {
 // one stream wait, from a small per-device ring of timing-disabled events.  Capturable: inside a stream capture the pair
 // becomes a dependency edge of the graph, exactly as torch's Stream.wait_stream does - without its ~13 us of Python.
 extern "C" int eslam_stream_wait(eslam_stream_t waiter, eslam_stream_t signaler) {
-    constexpr int RING = 64, MAXDEV = 16;
+    // Called from the Python thread AND from autograd's engine thread (ctypes drops the GIL around the call): the ring
+    // index is atomic and each device's events are created exactly once.
+    constexpr int RING = 64, MAXDEV = 64;
     static hipEvent_t ring[MAXDEV][RING];
-    static unsigned next[MAXDEV];
-    static bool ready[MAXDEV];
+    static std::atomic<unsigned> next[MAXDEV];
+    static std::once_flag made[MAXDEV];
+    static bool ok[MAXDEV];
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) {
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) {
         eslam_set_error("eslam_stream_wait: no usable current device");
         return 2;
     }
-    if (!ready[dev]) {
-        for (int i = 0; i < RING; ++i)
-            if (hipEventCreateWithFlags(&ring[dev][i], hipEventDisableTiming) != hipSuccess) {
-                eslam_set_error("eslam_stream_wait: hipEventCreateWithFlags failed");
-                return 2;
-            }
-        ready[dev] = true;
+    if (dev >= MAXDEV) {          // no ring for this device index: an event of its own, released once the wait is enqueued
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+            eslam_set_error("eslam_stream_wait: hipEventCreateWithFlags failed");
+            return 2;
+        }
+        const bool fine = hipEventRecord(ev, (hipStream_t)signaler) == hipSuccess &&
+                          hipStreamWaitEvent((hipStream_t)waiter, ev, 0) == hipSuccess;
+        (void)hipEventDestroy(ev);       // deferred by the runtime until the recorded work has completed
+        if (!fine) {
+            eslam_set_error("eslam_stream_wait: %s", hipGetErrorString(hipGetLastError()));
+            return 2;
+        }
+        return 0;
     }
-    hipEvent_t ev = ring[dev][next[dev]++ % RING];
+    std::call_once(made[dev], [dev] {
+        bool good = true;
+        for (int i = 0; i < RING; ++i) good = good && hipEventCreateWithFlags(&ring[dev][i], hipEventDisableTiming) == hipSuccess;
+        ok[dev] = good;
+    });
+    if (!ok[dev]) {
+        eslam_set_error("eslam_stream_wait: hipEventCreateWithFlags failed");
+        return 2;
+    }
+    hipEvent_t ev = ring[dev][next[dev].fetch_add(1u, std::memory_order_relaxed) % RING];
     if (hipEventRecord(ev, (hipStream_t)signaler) != hipSuccess || hipStreamWaitEvent((hipStream_t)waiter, ev, 0) != hipSuccess) {
         eslam_set_error("eslam_stream_wait: %s", hipGetErrorString(hipGetLastError()));
         return 2;

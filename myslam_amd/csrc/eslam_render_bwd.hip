@@ -712,8 +712,8 @@ static Bound make_bound(const float* b6) {
 
 int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float* rays_o, const float* rays_d,
                      const float* z_or_pts, int64_t R, int S, bool render, const float* g_feat, const int* perm,
-                     hipStream_t st, unsigned* records, int phase, const DecReduceArgs* red);
-bool eslam_scatter_can_reduce(bool render, int phase);
+                     hipStream_t st, const DecReduceArgs* red);
+bool eslam_scatter_can_reduce(bool render);
 
 
 static int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
@@ -734,7 +734,7 @@ extern "C" int64_t eslam_bwd_workspace_bytes(int64_t n_points) {
 static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, const Bound& bnd, const float* rays_o,
                       const float* rays_d, const float* z_or_pts, int64_t R, int S, int mode, const float* feat,
                       float* g_o, float* g_feat, float* slabs, const int* perm, float* g_dec, float* g_out_a, float* g_out_b,
-                      RayBwdIn rb, const LossGradIn* li, float* g_beta, const void* scatter_records, hipStream_t st) {
+                      RayBwdIn rb, const LossGradIn* li, float* g_beta, hipStream_t st) {
     const bool render = mode != 0;
     const int64_t N = render ? R * S : R;
     PlaneSet ps;
@@ -782,8 +782,7 @@ static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, 
     red.beta_parts = render ? beta_parts : nullptr; red.n_beta_parts = n_beta_parts; red.g_beta = g_beta;
     // The slab reduction (44 workgroups, latency-bound, ~7 us as a launch of its own) rides in the scatter's grid when there
     // is one: its workgroups run beside the scatter's first ones instead of in front of them.
-    const int phase = scatter_records ? 2 : 0;
-    const bool fold = g_dec && any_grad && eslam_scatter_can_reduce(render, phase);
+    const bool fold = g_dec && any_grad && eslam_scatter_can_reduce(render);
     if (g_dec && !fold) {
         eslam_prof_begin(PROF_DEC_REDUCE, st);
         hipLaunchKernelGGL(dec_grad_reduce_kernel, dim3(DEC_RED_COLBLOCKS, 2), dim3(1024), 0, st, red);
@@ -797,8 +796,7 @@ static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, 
     // plane gradients
     if (any_grad) {
         eslam_prof_begin(PROF_SCATTER, st);
-        if (int rc = eslam_scatter_v2(planes, bnd, rays_o, rays_d, z_or_pts, R, S, render, g_feat, perm, st,
-                                      (unsigned*)scatter_records, phase, fold ? &red : nullptr))
+        if (int rc = eslam_scatter_v2(planes, bnd, rays_o, rays_d, z_or_pts, R, S, render, g_feat, perm, st, fold ? &red : nullptr))
             return rc;
         eslam_prof_end(PROF_SCATTER, st);
     }
@@ -825,13 +823,9 @@ static int render_bwd_impl(const char* who, const eslam_plane_t* planes, const e
                            const float* bound6_host, const float* rays_o, const float* rays_d, const float* z_vals, int R,
                            int S, const float* sdf, const float* raw_rgb, const float* feat, const float* g_depth,
                            const float* g_rgb, const float* g_sdf, const LossGradIn* li, float* g_dec, float* g_beta,
-                           float* g_rays_o, float* g_rays_d, const int32_t* ray_order, const void* scatter_records,
-                           void* workspace, eslam_stream_t stream) {
+                           float* g_rays_o, float* g_rays_d, const int32_t* ray_order, void* workspace,
+                           eslam_stream_t stream) {
     if (R <= 0) return 0;
-    if (scatter_records && !ray_order) {
-        eslam_set_error("%s: scatter_records come from eslam_scatter_prep, which was given a ray_order: pass it here too", who);
-        return 1;
-    }
     if (S <= 0 || S > ESLAM_MAX_SAMPLES) {
         eslam_set_error("%s: S=%d outside [1,%d]", who, S, ESLAM_MAX_SAMPLES);
         return 1;
@@ -866,18 +860,16 @@ static int render_bwd_impl(const char* who, const eslam_plane_t* planes, const e
     rb.z_vals = z_vals; rb.sdf = sdf; rb.raw_rgb = raw_rgb; rb.beta = dec->beta;
     rb.g_depth = g_depth; rb.g_rgb = g_rgb; rb.g_sdf = g_sdf; rb.R = R; rb.S = S;
     return bwd_common(planes, dec, bnd, rays_o, rays_d, z_vals, R, S, li ? 2 : 1, feat, g_o, g_feat, slabs, perm, g_dec,
-                      g_rays_o, g_rays_d, rb, li, g_beta, scatter_records, st);
+                      g_rays_o, g_rays_d, rb, li, g_beta, st);
 }
 
 extern "C" int eslam_render_bwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
                                 const float* rays_o, const float* rays_d, const float* z_vals, int R, int S,
                                 const float* sdf, const float* raw_rgb, const float* feat, const float* g_depth,
                                 const float* g_rgb, const float* g_sdf, float* g_dec, float* g_beta, float* g_rays_o,
-                                float* g_rays_d, const int32_t* ray_order, const void* scatter_records, void* workspace,
-                                eslam_stream_t stream) {
+                                float* g_rays_d, const int32_t* ray_order, void* workspace, eslam_stream_t stream) {
     return render_bwd_impl("eslam_render_bwd", planes, dec, bound6_host, rays_o, rays_d, z_vals, R, S, sdf, raw_rgb, feat,
-                           g_depth, g_rgb, g_sdf, nullptr, g_dec, g_beta, g_rays_o, g_rays_d, ray_order, scatter_records,
-                           workspace, stream);
+                           g_depth, g_rgb, g_sdf, nullptr, g_dec, g_beta, g_rays_o, g_rays_d, ray_order, workspace, stream);
 }
 
 extern "C" int eslam_render_bwd_loss(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
@@ -887,8 +879,7 @@ extern "C" int eslam_render_bwd_loss(const eslam_plane_t* planes, const eslam_de
                                      const float* weights5_host, const uint8_t* ray_mask, const float* acc,
                                      const float* upstream, float* loss_out, const float* g_depth, const float* g_rgb,
                                      const float* g_sdf, float* g_dec, float* g_beta, float* g_rays_o, float* g_rays_d,
-                                     const int32_t* ray_order, const void* scatter_records, void* workspace,
-                                     eslam_stream_t stream) {
+                                     const int32_t* ray_order, void* workspace, eslam_stream_t stream) {
     if (!depth || !rgb || !gt_depth || !gt_color || !weights5_host || !acc) {
         eslam_set_error("eslam_render_bwd_loss: null loss argument");
         return 1;
@@ -899,8 +890,7 @@ extern "C" int eslam_render_bwd_loss(const eslam_plane_t* planes, const eslam_de
     li.tr = make_trunc(truncation);
     li.w = LossW{weights5_host[0], weights5_host[1], weights5_host[2], weights5_host[3], weights5_host[4]};
     return render_bwd_impl("eslam_render_bwd_loss", planes, dec, bound6_host, rays_o, rays_d, z_vals, R, S, sdf, raw_rgb,
-                           feat, g_depth, g_rgb, g_sdf, &li, g_dec, g_beta, g_rays_o, g_rays_d, ray_order, scatter_records,
-                           workspace, stream);
+                           feat, g_depth, g_rgb, g_sdf, &li, g_dec, g_beta, g_rays_o, g_rays_d, ray_order, workspace, stream);
 }
 
 extern "C" int eslam_decode_bwd(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
@@ -925,5 +915,5 @@ extern "C" int eslam_decode_bwd(const eslam_plane_t* planes, const eslam_decoder
     hipLaunchKernelGGL(decode_act_bwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, raw, g_raw, N, g_o);
     if (int rc = eslam_check_launch("decode_act_bwd_kernel")) return rc;
     return bwd_common(planes, dec, bnd, nullptr, nullptr, pts, N, 64, 0, feat, g_o, g_feat, slabs, nullptr, g_dec,
-                      g_pts, nullptr, RayBwdIn{}, nullptr, nullptr, nullptr, st);
+                      g_pts, nullptr, RayBwdIn{}, nullptr, nullptr, st);
 }

@@ -168,8 +168,10 @@ struct RngArg {
     const uint32_t* state;       // [1] step counter on the device, or NULL (step 0)
     int on;                      // 0: numbers come from the t_rand / t_rand_uni / u arrays
     int perturb;                 // jitter the samples (Renderer.perturb); the importance draw u is needed either way
+    uint32_t ray_offset;         // index of this call's ray 0 in the iteration's WHOLE batch: the numbers are keyed on the global
+                                 // ray index, so a ray-sharded iteration draws what the unsharded one does
 };
-struct Rng { uint32_t k0, k1; bool on, perturb; };
+struct Rng { uint32_t k0, k1; bool on, perturb; uint32_t ray_offset; };
 
 __device__ __forceinline__ uint32_t mix32(uint32_t h) {
     h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
@@ -182,6 +184,7 @@ __device__ __forceinline__ Rng make_rng(const RngArg a) {
     r.k1 = a.seed_hi + step * 0x7F4A7C15u;
     r.on = a.on != 0;
     r.perturb = a.perturb != 0;
+    r.ray_offset = a.ray_offset;
     return r;
 }
 __device__ __forceinline__ float rng_uniform(const Rng& r, uint32_t stream, uint32_t idx) {
@@ -221,8 +224,10 @@ __device__ __forceinline__ int count_lt_sorted(const float* a, int n, float v) {
 // one wave: the S depth-guided samples of one ray with depth d > 0 (zs: S floats of LDS owned by the wave)
 __device__ __forceinline__ void depth_guided_row(float d, int ray, int n_strat, int n_imp, float c15, float c3,
                                                  const float* __restrict__ t_free, const float* __restrict__ t_surf,
-                                                 const float* __restrict__ t_rand, float* __restrict__ z_vals, float* zs,
+                                                 const float* __restrict__ t_rand, float* __restrict__ out, float* zs,
                                                  int lane, const Rng& rng) {
+    // out: the ray's row of z_vals (or an LDS row: eslam_loss_set_sizes); `ray` indexes t_rand and, with rng.ray_offset, the
+    // in-kernel random numbers
     const int S = n_strat + n_imp;
     const float d12 = __fmul_rn(1.2f, d);          // Renderer.py:100
     const float dlo = __fsub_rn(d, c15);           // Renderer.py:97
@@ -260,10 +265,9 @@ __device__ __forceinline__ void depth_guided_row(float d, int ray, int n_strat, 
         zs[pos] = val;
     }
     WAVE_SYNC();
-    float* out = z_vals + (int64_t)ray * S;
     for (int i = lane; i < S; i += WAVE)
         out[i] = t_rand ? jitter_one(zs, i, S, t_rand[(int64_t)ray * S + i])
-                        : (rng.on && rng.perturb) ? jitter_one(zs, i, S, rng_uniform(rng, 0u, (uint32_t)(ray * S + i))) : zs[i];
+                        : (rng.on && rng.perturb) ? jitter_one(zs, i, S, rng_uniform(rng, 0u, (rng.ray_offset + (uint32_t)ray) * (uint32_t)S + (uint32_t)i)) : zs[i];
 }
 
 __global__ __launch_bounds__(256) void sample_z_kernel(const float* __restrict__ gt_depth, int R, int n_strat,
@@ -277,7 +281,8 @@ __global__ __launch_bounds__(256) void sample_z_kernel(const float* __restrict__
     if (ray >= R) return;
     const float d = gt_depth[ray];
     if (!(d > 0.0f)) return;                       // Renderer.py:92: handled by the importance sampler
-    depth_guided_row(d, ray, n_strat, n_imp, c15, c3, t_free, t_surf, t_rand, z_vals, zs_all[wave], lane, Rng{0u, 0u, false, false});
+    depth_guided_row(d, ray, n_strat, n_imp, c15, c3, t_free, t_surf, t_rand, z_vals + (int64_t)ray * (n_strat + n_imp), zs_all[wave], lane,
+                     Rng{0u, 0u, false, false, 0u});
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void importance_z_kernel(const PlaneSet pla
     const float d0 = gt_depth[ray];
     if (d0 > 0.0f) {                                 // uniform over the workgroup
         if (WITH_DEPTH && wave == 0)
-            depth_guided_row(d0, ray, n_strat, n_imp, c15, c3, t_free, t_surf, t_rand, z_vals, zu, lane, rng);
+            depth_guided_row(d0, ray, n_strat, n_imp, c15, c3, t_free, t_surf, t_rand, z_vals + (int64_t)ray * (n_strat + n_imp), zu, lane, rng);
         return;
     }
     stage_decoder_weights_one(wlds, dec, 0, threadIdx.x, blockDim.x);
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void importance_z_kernel(const PlaneSet pla
     __syncthreads();                                 // (also: the decoder weights are staged)
     for (int i = threadIdx.x; i < n_strat; i += 256)
         zu[i] = t_rand_uni ? jitter_one(wt, i, n_strat, t_rand_uni[(int64_t)ray * n_strat + i])
-                           : (rng.on && rng.perturb) ? jitter_one(wt, i, n_strat, rng_uniform(rng, 1u, (uint32_t)(ray * n_strat + i))) : wt[i];
+                           : (rng.on && rng.perturb) ? jitter_one(wt, i, n_strat, rng_uniform(rng, 1u, (rng.ray_offset + (uint32_t)ray) * (uint32_t)n_strat + (uint32_t)i)) : wt[i];
     __syncthreads();
 
     // SDF decode of the n_strat points (geometry planes only) -> alpha (Renderer.py:122-127); wave w takes blocks w, w+4, ...
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void importance_z_kernel(const PlaneSet pla
     }
     WAVE_SYNC();
     for (int i = lane; i < n_imp; i += WAVE) {
-        const float u = u_rand ? u_rand[(int64_t)ray * n_imp + i] : rng_uniform(rng, 2u, (uint32_t)(ray * n_imp + i));
+        const float u = u_rand ? u_rand[(int64_t)ray * n_imp + i] : rng_uniform(rng, 2u, (rng.ray_offset + (uint32_t)ray) * (uint32_t)n_imp + (uint32_t)i);
         // searchsorted(cdf, u, right=True): #entries <= u; the cdf is a cumsum of weights >= 0 (alpha in [0,1]): non-decreasing
         const int inds = count_le_sorted(wt, nb, u);
         const int below = max(inds - 1, 0);
@@ -433,6 +438,77 @@ __global__ __launch_bounds__(256, 2) void importance_z_kernel(const PlaneSet pla
         }
         out_row[pos] = v;
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// The five set sizes the mapping loss takes its means over (src/Mapper.py:136-140,343,346) for a WHOLE batch of rays,
+// without rendering it: they depend on gt_depth and on the depth-guided z_vals of the rays WITH depth only (a depth-less ray
+// counts towards the colour term alone), i.e. on K3 - replayed here into LDS, same arithmetic and same random numbers as
+// importance_z_kernel<., true> / sample_z_kernel write to memory, and classified with the loss's own region rule.  Every
+// rank of a ray-sharded iteration runs this on the iteration's whole batch instead of all-reducing its shard's counts
+// ("compute them redundantly on every rank"): no collective between forward and backward.
+// acc_out [16]: the count slots (N_front, N_center, N_tail, N_depth, N_color) as floats, every other slot 0.
+// scratch: 7 lines of 32 unsigned, zeroed once by the caller; left zeroed.
+// ---------------------------------------------------------------------------------------------------------
+#include "eslam_loss_final.h"
+__global__ __launch_bounds__(256) void loss_set_sizes_kernel(const float* __restrict__ gt_depth, const uint8_t* __restrict__ ray_mask,
+                                                            int R, int n_strat, int n_imp, float c15, float c3,
+                                                            const float* __restrict__ t_free, const float* __restrict__ t_surf,
+                                                            const float* __restrict__ t_rand, const RngArg rng_arg, const Trunc tr,
+                                                            unsigned* __restrict__ scratch, float* __restrict__ acc_out) {
+    const Rng rng = make_rng(rng_arg);
+    __shared__ float zs_all[4][ESLAM_MAX_SAMPLES];
+    __shared__ float zo_all[4][ESLAM_MAX_SAMPLES];
+    __shared__ unsigned part[4][5];
+    __shared__ unsigned ticket;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int S = n_strat + n_imp;
+    unsigned cnt[5] = {0u, 0u, 0u, 0u, 0u};                    // front, center, tail, depth, colour: this lane's share
+    for (int ray = blockIdx.x * 4 + wave; ray < R; ray += gridDim.x * 4) {
+        if (ray_mask && ray_mask[ray] == 0) continue;          // (uniform over the wave)
+        if (lane == 0) cnt[4] += 3u;
+        const float d = gt_depth[ray];
+        if (!(d > 0.0f)) continue;
+        if (lane == 0) cnt[3] += 1u;
+        depth_guided_row(d, ray, n_strat, n_imp, c15, c3, t_free, t_surf, t_rand, zo_all[wave], zs_all[wave], lane, rng);
+        WAVE_SYNC();
+        for (int i = lane; i < S; i += WAVE) {
+            const int reg = sdf_region(zo_all[wave][i], d, tr);
+            if (reg < 3) cnt[reg] += 1u;
+        }
+        WAVE_SYNC();
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const unsigned t = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_sum_u(cnt[k]), WAVE - 1);
+        if (lane == 0) part[wave][k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        const unsigned tot = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        if (tot) {
+            const unsigned old = atomicAdd(scratch + 32 * (threadIdx.x + 1), tot);
+            asm volatile("" ::"v"(old));                       // performed once its result is back (as loss_finalize)
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) ticket = atomicAdd(scratch, 1u);
+    __syncthreads();
+    if (ticket != gridDim.x - 1) return;
+    if (threadIdx.x < 16) {
+        float v = 0.0f;
+        int k = -1;
+        if (threadIdx.x == A_N_FRONT) k = 0;
+        else if (threadIdx.x == A_N_CENTER) k = 1;
+        else if (threadIdx.x == A_N_TAIL) k = 2;
+        else if (threadIdx.x == A_N_DEPTH) k = 3;
+        else if (threadIdx.x == A_N_COLOR) k = 4;
+        if (k >= 0) v = (float)atomicExch(scratch + 32 * (k + 1), 0u);
+        acc_out[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) atomicExch(scratch, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -621,10 +697,44 @@ extern "C" int eslam_sample_z_all(const eslam_plane_t* planes, const eslam_decod
 extern "C" int eslam_sample_z_all_rng(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
                                       const float* rays_o, const float* rays_d, const float* gt_depth, int R, int n_strat,
                                       int n_imp, double truncation, const float* t_free, const float* t_surf, int perturb,
-                                      uint64_t seed, const uint32_t* rng_state, float* z_vals, eslam_stream_t stream) {
+                                      uint64_t seed, const uint32_t* rng_state, int64_t ray_offset, float* z_vals,
+                                      eslam_stream_t stream) {
+    if (ray_offset < 0 || (ray_offset + (int64_t)(R > 0 ? R : 0)) * (n_strat + n_imp) >= ((int64_t)1 << 32)) {
+        eslam_set_error("eslam_sample_z_all_rng: ray_offset %lld out of range", (long long)ray_offset);
+        return 1;
+    }
     RngArg rng;
     rng.seed_lo = (uint32_t)seed; rng.seed_hi = (uint32_t)(seed >> 32); rng.state = rng_state; rng.on = 1;
     rng.perturb = perturb ? 1 : 0;
+    rng.ray_offset = (uint32_t)ray_offset;
     return sample_z_all_impl("eslam_sample_z_all_rng", planes, dec, bound6_host, rays_o, rays_d, gt_depth, R, n_strat, n_imp,
                              truncation, t_free, t_surf, nullptr, nullptr, nullptr, rng, z_vals, stream);
+}
+
+extern "C" int eslam_loss_set_sizes(const float* gt_depth, const uint8_t* ray_mask, int R, int n_strat, int n_imp,
+                                    double truncation, const float* t_free, const float* t_surf, const float* t_rand, int perturb,
+                                    uint64_t seed, const uint32_t* rng_state, uint32_t* scratch, float* acc_out,
+                                    eslam_stream_t stream) {
+    if (R <= 0 || n_strat < 1 || n_imp < 0 || n_strat + n_imp > ESLAM_MAX_SAMPLES) {
+        eslam_set_error("eslam_loss_set_sizes: R=%d n_strat=%d n_imp=%d unsupported", R, n_strat, n_imp);
+        return 1;
+    }
+    if (!gt_depth || !t_free || (n_imp > 0 && !t_surf) || !scratch || !acc_out) {
+        eslam_set_error("eslam_loss_set_sizes: null argument");
+        return 1;
+    }
+    if ((int64_t)R * (n_strat + n_imp) >= ((int64_t)1 << 32)) {
+        eslam_set_error("eslam_loss_set_sizes: batch too large");
+        return 1;
+    }
+    RngArg rng = {};
+    if (!t_rand) {
+        rng.seed_lo = (uint32_t)seed; rng.seed_hi = (uint32_t)(seed >> 32); rng.state = rng_state; rng.on = 1;
+        rng.perturb = perturb ? 1 : 0;
+    }
+    const int nwg = (R + 3) / 4 < 1024 ? (R + 3) / 4 : 1024;
+    hipLaunchKernelGGL(loss_set_sizes_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, gt_depth, ray_mask, R, n_strat, n_imp,
+                       (float)(1.5 * truncation), (float)(3.0 * truncation), t_free, t_surf, t_rand, rng, make_trunc(truncation),
+                       scratch, acc_out);
+    return eslam_check_launch("loss_set_sizes_kernel");
 }

@@ -20,6 +20,7 @@
 //                     lane = (x-corner, channel): consecutive entries of one cell are summed in two registers (rows
 //                     y0, y1) and each cell is written once with two 256-B-shaped float atomics.
 #include <stdlib.h>
+#include <mutex>
 #include <type_traits>
 #include "eslam_decode_tile.h"
 #include "eslam_dec_reduce.h"
@@ -255,22 +256,20 @@ __global__ __launch_bounds__(1024) void ray_order_kernel(const float* __restrict
 // NT threads per workgroup, BM = 4*NT samples per workgroup (power of two).
 //   DBG: 0 production; 1 walk without atomics; 2 stop after the sort; 3 = 1 without the g_feat row loads; 4 = 3 without the
 //   LDS weight reads (profiling only, tools/scatter_anatomy.sh)
-//   PHASE: 0 = cells + sort + walk in one launch.  The cells and the sort depend on the sample POSITIONS only, not on the
-//   feature gradients, so they can run long before the backward pass, beside the forward kernel on another stream:
-//   PHASE 1 (eslam_scatter_prep) stops after the sort and writes the workgroup's sorted record image (the 6*BM words of
-//   LDS + one word of flags) to `records`; PHASE 2 (inside eslam_render_bwd) reads that image back - 48 KB of coalesced
-//   loads instead of 33 us of latency-bound cell arithmetic and sorting in front of the first atomic - and walks it.
+//   (Round 2 had the kernel's two halves - cells + sort / walk - as separately launchable phases, the first one beside the
+//   forward kernel on a side stream: 0.369 vs 0.323 ms per step, DESIGN.md section 10.  Removed in round 3.)
 #ifndef SC_STAMPS
 #define SC_STAMPS 0                                   // profiling only: per-phase cycles of one workgroup's first thread
 #endif
-#define REC_META 4                                   // words behind the LDS image: [0] = swap | valid << 1
 //   DET (ESLAM_DETERMINISTIC=1): the sums of a cell are formed in 64-bit fixed point (2^-44 units: integer adds commute, so
 //   neither the arbitrary order of the counting sort's tickets inside a cell, nor the order in which workgroups' atomics
 //   reach a texel, nor the ray order itself can change a bit of the result) and added to an int64 shadow of the gradient
 //   planes; scatter_fixed_to_float_kernel then adds the shadow to the float gradients and clears it.
-#define FIX_SCALE 17592186044416.0f                  // 2^44: |contribution| < 5e5, resolution 5.7e-14
+#define FIX_SCALE 17592186044416.0f                  // 2^44: resolution 5.7e-14
+#define FIX_LIMIT 262144.0f                          // |one contribution| < 2^18: 2^62 in fixed point; a texel's SUM wraps beyond
+                                                     // 2^63 / 2^44 = 5.2e5 - contributions past the limit poison the gradient (NaN)
 struct ShadowOff { int64_t o[NPL]; };
-template <bool RENDER, int DBG, int NT, int PHASE, bool DET, int SPT = 4>
+template <bool RENDER, int DBG, int NT, bool DET, int SPT = 4>
 __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes, const Bound bnd,
                                                           const float* __restrict__ rays_o,
                                                           const float* __restrict__ rays_d,
@@ -278,7 +277,7 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
                                                           const int* __restrict__ perm, int R, int S,
                                                           const float* __restrict__ g_feat, int bundle,
                                                           int allow_counting, int nbundles, int xcd_map,
-                                                          unsigned* __restrict__ records, long long* __restrict__ shadow,
+                                                          long long* __restrict__ shadow,
                                                           const ShadowOff shoff, const DecReduceArgs red, const int red_blocks) {
     constexpr int dbg_mode = DBG;
     constexpr int BM = SPT * NT;                       // SPT samples per thread in the cell / sort phases
@@ -354,16 +353,7 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
 #else
 #define SSTAMP(i)
 #endif
-    unsigned* const rimg = (PHASE != 0) ? records + ((size_t)bidx * NPL + pi) * (6 * BM + REC_META) : nullptr;
     bool swap = false;
-    if (PHASE == 2) {
-        // the sorted record image of this (bundle, plane), as eslam_scatter_prep left it
-        const unsigned meta = rimg[6 * BM];
-        if (!(meta & 2u)) return;                                         // no valid sample in this bundle
-        swap = (meta & 1u) != 0;
-        for (int i = threadIdx.x; i < 6 * BM / 4; i += NT) ((uint4*)lds_raw)[i] = ((const uint4*)rimg)[i];
-        __syncthreads();
-    } else {
     if (threadIdx.x == 0) { sbox[0] = 0x7FFFFFFF; sbox[1] = -1; sbox[2] = 0x7FFFFFFF; sbox[3] = -1; }
     __syncthreads();
 
@@ -412,10 +402,7 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
     // of the sorted list are neighbours along it and share a texel column that is carried instead of flushed twice.
     const int bxmin = sbox[0], bxmax = sbox[1], bymin = sbox[2], bymax = sbox[3];
     __syncthreads();                                                  // sbox's memory is reused from here on
-    if (bxmax < 0) {                                                  // no valid sample in this bundle
-        if (PHASE == 1 && threadIdx.x == 0) rimg[6 * BM] = 0u;
-        return;
-    }
+    if (bxmax < 0) return;                                            // no valid sample in this bundle
     swap = (bymax - bymin) > (bxmax - bxmin);                         // travels along y: column-major keys
     // Bundles whose cells fit a small box (the normal case: 32 neighbouring rays) are ordered by a counting sort over
     // the box - one LDS integer atomic per sample, one scan, one placement pass - instead of the 66-stage bitonic
@@ -568,12 +555,6 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
     }
     __syncthreads();
     }
-    if (PHASE == 1) {
-        for (int i = threadIdx.x; i < 6 * BM / 4; i += NT) ((uint4*)rimg)[i] = ((const uint4*)lds_raw)[i];
-        if (threadIdx.x == 0) rimg[6 * BM] = (swap ? 1u : 0u) | 2u;
-        return;
-    }
-    }       // PHASE != 2
     SSTAMP(4)
     if (dbg_mode == 2) return;
 
@@ -590,6 +571,7 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
     unsigned last_xy = PAD_XY;                 // xy of the last entry of the previous block
     typedef typename std::conditional<DET, long long, float>::type acc_t;
     acc_t acc0 = 0, acc1 = 0;
+    bool det_bad = false;                      // DET: a contribution of the current cell was not representable
     const int e0 = wave * CH;
 
     // Flush of a finished cell: lane (hx, c) adds its two sums (major-axis corners 0 and 1) for its minor-axis corner.
@@ -607,6 +589,12 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
                 if (!lower_half_only || hx == 0) {           // the shadow mirrors the plane element for element: 8 bytes each
                     atomicAdd((unsigned long long*)(gbytes + 2 * (size_t)o0), (unsigned long long)acc0);
                     atomicAdd((unsigned long long*)(gbytes + 2 * (size_t)o1), (unsigned long long)acc1);
+                    // a contribution that was NaN / Inf or beyond the fixed-point range (|g w| >= 2.6e5; __float2ll_rn would
+                    // have saturated or wrapped it silently): poison the float gradient so that divergence stays visible
+                    if (det_bad) {
+                        atomicAdd((float*)((char*)grad + o0), __builtin_nanf(""));
+                        atomicAdd((float*)((char*)grad + o1), __builtin_nanf(""));
+                    }
                 }
             } else if (dbg_mode == 0) {
                 if (!lower_half_only || hx == 0) {
@@ -653,12 +641,13 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
         if (((idx < 32 ? fresh_lo : fresh_hi) >> (idx & 31)) & 1u) {     /* one s_bitcmp on a 32-bit scalar */ \
             if (((idx < 32 ? adj_lo : adj_hi) >> (idx & 31)) & 1u) {                          \
                 /* next cell along the minor axis: its first texel column is our second one - keep those sums */ \
-                flush(true);                                                                  \
+                flush(true);          /* (det_bad stays: the carried column holds part of the cell's sums) */ \
                 const acc_t s0 = __shfl_xor(acc0, 32, WAVE), s1 = __shfl_xor(acc1, 32, WAVE); \
                 acc0 = hx ? (acc_t)0 : s0;                                                    \
                 acc1 = hx ? (acc_t)0 : s1;                                                    \
             } else {                                                                          \
                 flush(false);                                                                 \
+                det_bad = false;                                                              \
                 acc0 = 0;                                                                     \
                 acc1 = 0;                                                                     \
             }                                                                                 \
@@ -666,8 +655,10 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
         }                                                                                     \
         const float g = buf[t];        /* padding entries have zero weights and belong to no cell */ \
         if (DET) {                                                                            \
-            acc0 += (acc_t)__float2ll_rn((g * w2[0]) * FIX_SCALE);                            \
-            acc1 += (acc_t)__float2ll_rn((g * w2[1]) * FIX_SCALE);                            \
+            const float t0_ = g * w2[0], t1_ = g * w2[1];                                     \
+            det_bad = det_bad || !(fabsf(t0_) < FIX_LIMIT) || !(fabsf(t1_) < FIX_LIMIT);      \
+            acc0 += (acc_t)__float2ll_rn(t0_ * FIX_SCALE);                                    \
+            acc1 += (acc_t)__float2ll_rn(t1_ * FIX_SCALE);                                    \
         } else {                                                                              \
             acc0 += (acc_t)(g * w2[0]);                                                       \
             acc1 += (acc_t)(g * w2[1]);                                                       \
@@ -844,27 +835,17 @@ static int scatter_bundle_size(int S, bool render, int* bm_out) {
     return *bm_out / (render ? S : 64);
 }
 
-// bytes of the record images eslam_scatter_prep writes for R rays x S samples
-extern "C" int64_t eslam_scatter_records_bytes(int R, int S) {
-    if (R <= 0 || S <= 0 || S > ESLAM_MAX_SAMPLES) return -1;
-    int bm;
-    const int bundle = scatter_bundle_size(S, true, &bm);
-    const int64_t nbundles = (R + bundle - 1) / bundle;
-    return nbundles * NPL * (6 * (int64_t)bm + REC_META) * 4;
-}
-
 // whether the scatter launch of this mode can also run the decoder-gradient slab reduction (the production render path: one
 // kernel, XCD-mapped 1-D grid, 512 threads); the stand-alone dec_grad_reduce_kernel covers the rest
-bool eslam_scatter_can_reduce(bool render, int phase) {
+bool eslam_scatter_can_reduce(bool render) {
     static const int xcd_map = env_int("ESLAM_SC_XCDMAP", 1), dbg_mode = env_int("ESLAM_SC_MODE", 0), bm = env_int("ESLAM_SC_BUNDLE", 2048);
     static const int off = env_int("ESLAM_SC_NO_REDUCE", 0);
-    return render && phase == 0 && !eslam_deterministic() && xcd_map && dbg_mode == 0 && bm != 1024 && !off;
+    return render && !eslam_deterministic() && xcd_map && dbg_mode == 0 && bm != 1024 && !off;
 }
 
-// phase 0: cells + sort + walk; 1: cells + sort -> records (g_feat unused); 2: walk of the records
 int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float* rays_o, const float* rays_d,
                      const float* z_or_pts, int64_t R, int S, bool render, const float* g_feat, const int* perm,
-                     hipStream_t st, unsigned* records, int phase, const DecReduceArgs* red) {
+                     hipStream_t st, const DecReduceArgs* red) {
     PlaneSet ps;
     for (int i = 0; i < NPL; ++i) {
         ps.p[i] = planes[i];
@@ -899,14 +880,13 @@ int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float*
         }
     static const int counting = env_int("ESLAM_SC_COUNTING", 1);   // A/B switch: 0 = always the bitonic network
     static const int xcd_map = env_int("ESLAM_SC_XCDMAP", 1);      // A/B switch: 0 = plain (bundle, plane) grid
-    static const int wide = env_int("ESLAM_SC_WIDE", 0);           // 1024 threads x 2 samples: a wave walks 128 entries, not 256
     const int nbundles = (nunits + bundle - 1) / bundle;
     dim3 grid(nbundles, NPL);
     if (xcd_map) grid = dim3(((nbundles * 4 + 7) / 8) * 8 * 3, 1);
     DecReduceArgs red_args = {};
     int red_blocks = 0;
     if (red) {
-        if (!eslam_scatter_can_reduce(render, phase)) {
+        if (!eslam_scatter_can_reduce(render)) {
             eslam_set_error("scatter: cannot carry the decoder-gradient reduction in this mode");
             return 1;
         }
@@ -914,15 +894,11 @@ int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float*
         red_blocks = (2 * DEC_RED_COLBLOCKS + 7) / 8 * 8;
         grid.x += red_blocks;
     }
-#define LAUNCH_SC(RD, DB, NTv, PH, PERM, SS)                                                                               \
-    hipLaunchKernelGGL((scatter_sort_kernel<RD, DB, NTv, PH, false>), grid, dim3(NTv), 0, st, ps, bnd, rays_o, rays_d, z_or_pts, \
-                       PERM, (int)R, SS, g_feat, bundle, counting, nbundles, xcd_map, records, (long long*)nullptr, ShadowOff{}, \
+#define LAUNCH_SC(RD, DB, NTv, PERM, SS)                                                                                   \
+    hipLaunchKernelGGL((scatter_sort_kernel<RD, DB, NTv, false>), grid, dim3(NTv), 0, st, ps, bnd, rays_o, rays_d, z_or_pts, \
+                       PERM, (int)R, SS, g_feat, bundle, counting, nbundles, xcd_map, (long long*)nullptr, ShadowOff{}, \
                        red_args, red_blocks)
-    if (phase != 0 && (!render || !records)) {
-        eslam_set_error("scatter: record phases need render mode and a record buffer");
-        return 1;
-    }
-    if (eslam_deterministic() && phase == 0) {
+    if (eslam_deterministic()) {
         // fixed-point scatter into the int64 shadow, then shadow -> float gradients (DET in the kernel's header comment)
         ShadowOff so;
         int64_t total = 0;
@@ -937,31 +913,46 @@ int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float*
             so.o[i] = total;
             total += numel;
         }
-        static long long* shadow = nullptr;
-        static int64_t shadow_n = 0;
-        if (shadow_n < total) {       // first use (an eager warm-up call; hipMalloc cannot be captured into a graph)
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            (void)hipStreamIsCapturing(st, &cs);
-            if (cs != hipStreamCaptureStatusNone) {
-                eslam_set_error("scatter (deterministic mode): run one eager iteration before capturing a graph");
-                return 1;
+        // One shadow per DEVICE (the pointer is a device allocation of the device that is current now).  A shadow that has
+        // been handed to a launch is never freed: a hipGraph captured earlier may still hold its address, so a larger scene
+        // gets a new allocation and the old one stays (a few scenes per process at most).
+        constexpr int MAXDEV = 64;
+        static long long* shadows[MAXDEV];
+        static int64_t shadow_ns[MAXDEV];
+        static std::mutex shadow_mu;
+        int devi = 0;
+        if (hipGetDevice(&devi) != hipSuccess || devi < 0 || devi >= MAXDEV) {
+            eslam_set_error("scatter (deterministic mode): no usable current device");
+            return 2;
+        }
+        long long* shadow;
+        {
+            std::lock_guard<std::mutex> lk(shadow_mu);
+            if (shadow_ns[devi] < total) {       // first use (an eager warm-up call; hipMalloc cannot be captured into a graph)
+                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                (void)hipStreamIsCapturing(st, &cs);
+                if (cs != hipStreamCaptureStatusNone) {
+                    eslam_set_error("scatter (deterministic mode): run one eager iteration before capturing a graph");
+                    return 1;
+                }
+                long long* fresh = nullptr;
+                if (hipMalloc(&fresh, (size_t)total * 8) != hipSuccess || hipMemset(fresh, 0, (size_t)total * 8) != hipSuccess) {
+                    eslam_set_error("scatter (deterministic mode): cannot allocate the %lld-element shadow", (long long)total);
+                    return 2;
+                }
+                shadows[devi] = fresh;           // (the previous, smaller one is deliberately kept alive: see above)
+                shadow_ns[devi] = total;
             }
-            if (shadow) (void)hipFree(shadow);
-            if (hipMalloc(&shadow, (size_t)total * 8) != hipSuccess || hipMemset(shadow, 0, (size_t)total * 8) != hipSuccess) {
-                shadow = nullptr; shadow_n = 0;
-                eslam_set_error("scatter (deterministic mode): cannot allocate the %lld-element shadow", (long long)total);
-                return 2;
-            }
-            shadow_n = total;
+            shadow = shadows[devi];
         }
         if (render)
-            hipLaunchKernelGGL((scatter_sort_kernel<true, 0, 512, 0, true>), grid, dim3(512), 0, st, ps, bnd, rays_o, rays_d,
-                               z_or_pts, perm, (int)R, S, g_feat, bundle, counting, nbundles, xcd_map, (unsigned*)nullptr, shadow, so,
+            hipLaunchKernelGGL((scatter_sort_kernel<true, 0, 512, true>), grid, dim3(512), 0, st, ps, bnd, rays_o, rays_d,
+                               z_or_pts, perm, (int)R, S, g_feat, bundle, counting, nbundles, xcd_map, shadow, so,
                                DecReduceArgs{}, 0);
         else
-            hipLaunchKernelGGL((scatter_sort_kernel<false, 0, 512, 0, true>), grid, dim3(512), 0, st, ps, bnd, rays_o, rays_d,
+            hipLaunchKernelGGL((scatter_sort_kernel<false, 0, 512, true>), grid, dim3(512), 0, st, ps, bnd, rays_o, rays_d,
                                z_or_pts, (const int*)nullptr, (int)R, 64, g_feat, bundle, counting, nbundles, xcd_map,
-                               (unsigned*)nullptr, shadow, so, DecReduceArgs{}, 0);
+                               shadow, so, DecReduceArgs{}, 0);
         if (int rc = eslam_check_launch("scatter_sort_kernel<det>")) return rc;
         for (int i = 0; i < NPL; ++i) {
             const int64_t numel = (int64_t)ESLAM_C_DIM * planes[i].h * planes[i].w;
@@ -971,20 +962,14 @@ int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float*
         return eslam_check_launch("scatter_fixed_to_float_kernel");
     }
     if (render) {
-        if (phase == 1) { if (bm == 1024) LAUNCH_SC(true, 0, 256, 1, perm, S); else LAUNCH_SC(true, 0, 512, 1, perm, S); }
-        else if (phase == 2) { if (bm == 1024) LAUNCH_SC(true, 0, 256, 2, perm, S); else LAUNCH_SC(true, 0, 512, 2, perm, S); }
-        else if (dbg_mode == 1) LAUNCH_SC(true, 1, 512, 0, perm, S);
-        else if (dbg_mode == 2) LAUNCH_SC(true, 2, 512, 0, perm, S);
-        else if (dbg_mode == 3) LAUNCH_SC(true, 3, 512, 0, perm, S);
-        else if (dbg_mode == 4) LAUNCH_SC(true, 4, 512, 0, perm, S);
-        else if (bm == 1024) LAUNCH_SC(true, 0, 256, 0, perm, S);
-        else if (wide) {
-            hipLaunchKernelGGL((scatter_sort_kernel<true, 0, 1024, 0, false, 2>), grid, dim3(1024), 0, st, ps, bnd, rays_o, rays_d,
-                               z_or_pts, perm, (int)R, S, g_feat, bundle, counting, nbundles, xcd_map, records, (long long*)nullptr,
-                               ShadowOff{}, red_args, red_blocks);
-        } else LAUNCH_SC(true, 0, 512, 0, perm, S);
+        if (dbg_mode == 1) LAUNCH_SC(true, 1, 512, perm, S);
+        else if (dbg_mode == 2) LAUNCH_SC(true, 2, 512, perm, S);
+        else if (dbg_mode == 3) LAUNCH_SC(true, 3, 512, perm, S);
+        else if (dbg_mode == 4) LAUNCH_SC(true, 4, 512, perm, S);
+        else if (bm == 1024) LAUNCH_SC(true, 0, 256, perm, S);
+        else LAUNCH_SC(true, 0, 512, perm, S);
     } else {
-        LAUNCH_SC(false, 0, 512, 0, (const int*)nullptr, 64);
+        LAUNCH_SC(false, 0, 512, (const int*)nullptr, 64);
     }
 #undef LAUNCH_SC
     return eslam_check_launch("scatter_sort_kernel");
@@ -992,25 +977,6 @@ int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float*
 
 bool eslam_planes_channels_last(const eslam_plane_t* planes, int first, int count);
 int eslam_validate_planes(const eslam_plane_t* planes, int first, int count);
-
-extern "C" int eslam_scatter_prep(const eslam_plane_t* planes, const float* bound6_host, const float* rays_o,
-                                  const float* rays_d, const float* z_vals, int R, int S, const int32_t* ray_order,
-                                  void* records, eslam_stream_t stream) {
-    if (R <= 0) return 0;
-    if (S <= 0 || S > ESLAM_MAX_SAMPLES) {
-        eslam_set_error("eslam_scatter_prep: S=%d outside [1,%d]", S, ESLAM_MAX_SAMPLES);
-        return 1;
-    }
-    if (!planes || !bound6_host || !rays_o || !rays_d || !z_vals || !ray_order || !records) {
-        eslam_set_error("eslam_scatter_prep: null argument");
-        return 1;
-    }
-    if (eslam_validate_planes(planes, 0, NPL)) return 1;
-    Bound bnd;
-    for (int k = 0; k < 3; ++k) { bnd.lo[k] = bound6_host[2 * k]; bnd.hi[k] = bound6_host[2 * k + 1]; }
-    return eslam_scatter_v2(planes, bnd, rays_o, rays_d, z_vals, R, S, true, nullptr, (const int*)ray_order,
-                            (hipStream_t)stream, (unsigned*)records, 1, nullptr);
-}
 
 int eslam_scatter_v2_init() {
     static bool done = false;

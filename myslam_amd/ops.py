@@ -110,6 +110,97 @@ def _alloc_plane_grads(planes, zero=True):
     return flat, [torch.as_strided(flat, shp, st, off) for shp, st, off in entries]
 
 
+def _flat_views(planes, memory_format):
+    """One uninitialised flat buffer + 12 views of the planes' shapes in `memory_format` (dense)."""
+    dev = planes[0].device
+    total = sum(p.numel() for p in planes)
+    flat = torch.empty(total, device=dev, dtype=torch.float32)
+    views, off = [], 0
+    for p in planes:
+        n, c, h, w = p.shape
+        st = (c * h * w, 1, c * w, c) if memory_format == torch.channels_last else (c * h * w, h * w, w, 1)
+        views.append(torch.as_strided(flat, tuple(p.shape), st, off))
+        off += p.numel()
+    return flat, views
+
+
+def _relayout(src, dst, field):
+    """eslam_planes_relayout between two lists of 12 tensors (field 0: values; field 1: the tensors are gradients)."""
+    dev = src[0].device
+    a, _ = _hip.make_planes(_split_planes(src), src if field else None)
+    b, _ = _hip.make_planes(_split_planes(dst), dst if field else None)
+    with _hip.on_device(dev):
+        _hip.check(_hip.lib().eslam_planes_relayout(a, b, int(field), _hip.stream_handle(dev)), "eslam_planes_relayout")
+
+
+class ChannelsLastFn(torch.autograd.Function):
+    """12 channels-last scratch copies = ChannelsLastFn.apply(*12 planes in the reference's NCHW layout, ESLAM.py:199-210).
+
+    Forward: one launch (eslam_planes_relayout).  Backward: the gradients the render kernels scattered into channels-last
+    buffers go back to the planes' own layout in one launch, so `p.grad.stride() == p.stride()` for the caller's optimiser.
+    Nothing is kept across calls: the mapper swaps the plane Parameters every frame (Mapper.py:254-266)."""
+
+    @staticmethod
+    def forward(ctx, *planes):
+        for k, p in enumerate(planes):
+            _hip.require_gpu_f32(f"plane {k}", p)
+            if not p.is_contiguous():
+                raise RuntimeError("planes must be dense (contiguous or channels_last)")
+        src = [p.detach() for p in planes]
+        _, views = _flat_views(src, torch.channels_last)
+        _relayout(src, views, 0)
+        ctx.shapes = [tuple(p.shape) for p in planes]
+        ctx.device = planes[0].device
+        return tuple(views)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        if all(g is None for g in grads):
+            return (None,) * 12
+        if any(g is None for g in grads):           # (the render backward produces all 12 or none)
+            grads = [g if g is not None else torch.zeros(shp, device=ctx.device).contiguous(memory_format=torch.channels_last)
+                     for g, shp in zip(grads, ctx.shapes)]
+        grads = [g if g.is_contiguous(memory_format=torch.channels_last) else g.contiguous(memory_format=torch.channels_last)
+                 for g in grads]
+        _, out = _flat_views(grads, torch.contiguous_format)
+        _relayout(list(grads), out, 1)
+        return tuple(out)
+
+
+# Planes in the reference's NCHW layout are copied to channels-last scratch per call when the batch has at least this many
+# points (below, the direct strided kernels are cheaper than moving 2 x 27-70 MB); ESLAM_NCHW_RELAYOUT_MIN=-1 disables it
+_RELAYOUT_MIN_POINTS = int(os.environ.get("ESLAM_NCHW_RELAYOUT_MIN", "4096"))
+
+
+_keep_layout = 0
+
+
+class keep_layout:
+    """Context manager: no per-call layout change inside (a caller that hands the kernels gradient buffers in the planes' own
+    strides - parallel.ShardedMapper's flat exchange buffer - needs the kernels to see the planes as they are)."""
+
+    def __enter__(self):
+        global _keep_layout
+        _keep_layout += 1
+
+    def __exit__(self, *a):
+        global _keep_layout
+        _keep_layout -= 1
+
+
+def planes_for_kernels(all_planes, n_points):
+    """all_planes as the kernels should see them: unchanged when channels-last (or the batch is small), else per-call
+    channels-last scratch copies that carry the gradient back to the caller's planes (ChannelsLastFn)."""
+    flat = [p for grp in all_planes for p in grp]
+    if _keep_layout or _RELAYOUT_MIN_POINTS < 0 or n_points < _RELAYOUT_MIN_POINTS or len(flat) != 12:
+        return all_planes
+    if all(p.dim() == 4 and p.shape[2] * p.shape[3] > 1 and p.is_contiguous(memory_format=torch.channels_last) for p in flat):
+        return all_planes
+    if not all(p.is_cuda and p.dtype == torch.float32 and p.dim() == 4 and p.is_contiguous() for p in flat):
+        return all_planes                     # let the kernels' own validation speak
+    return _split_planes(ChannelsLastFn.apply(*flat))
+
+
 _DEC_SIZES = [16 * 64, 16, 16 * 16, 16, 16, 1, 16 * 64, 16, 16 * 16, 16, 48, 3]
 
 
@@ -144,7 +235,7 @@ def ray_order_async(rays_o, rays_d, grad_planes=None):
         side = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
     perm = torch.empty(R, dtype=torch.int32, device=dev)
     pre = None
-    if grad_planes is not None and _PRECLEAR and _grad_sink is None:
+    if grad_planes is not None and _PRECLEAR and _grad_sink is None and not _keep_layout:      # (keep_layout: a sink will take the gradients)
         pre = _alloc_plane_grads(grad_planes, zero=False)      # on the caller's stream: its allocator's memory
     _hip.stream_wait(dev, side, None)           # the rays - and any earlier use of that memory - come from work on the caller's stream
     with _hip.on_device(dev):
@@ -164,15 +255,6 @@ def ray_order_async(rays_o, rays_d, grad_planes=None):
 # MI355X it is faster on the rays as given (119 vs 123-125 us at 4096x64 - sorted neighbours hit the same L2 channels).
 _FWD_USES_ORDER = os.environ.get("ESLAM_FWD_ORDER", "0") == "1"
 
-
-# ESLAM_SCATTER_SPLIT=1: the first half of the plane-gradient scatter (eslam_scatter_prep: cells + per-bundle sort, a
-# function of the sample positions only) runs on the ray-order side stream beside the forward kernel and the backward only
-# walks the sorted records.  OFF by default: measured on MI355X the walk-only kernel takes as long as the whole fused
-# kernel (121 vs 115 us at 4096 x 64 - with every workgroup walking at once the walk is bound by the feature-gradient
-# loads and the atomics, which the staggered phases of the fused kernel overlap with other workgroups' sorts), the 75 MB
-# of records cost their own traffic, and a replayed graph gains nothing from the side-stream branch: 0.369 vs 0.323 ms
-# per step.  Only launch-latency-bound batches profit in the kernel itself (200 x 32: 36 vs 51 us).  profiles/r02/.
-_SCATTER_SPLIT = os.environ.get("ESLAM_SCATTER_SPLIT", "0") == "1"
 
 _fused_loss = None
 
@@ -318,21 +400,6 @@ class RenderFn(torch.autograd.Function):
         fl = lossctx
         ctx.set_materialize_grads(False)
         ctx.lossctx = None
-        records = None
-        if (_SCATTER_SPLIT and needs and order_in is not None and not _FWD_USES_ORDER and
-                any(ctx.needs_input_grad[RenderFn.N_LEAD:RenderFn.N_LEAD + 12])):
-            # first half of the backward's scatter (cells + per-bundle sort: a function of the sample positions only) on
-            # the ray-order side stream, beside the forward kernel; joined in the backward with the order itself
-            nbytes = lib.eslam_scatter_records_bytes(R, S)
-            records = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            _hip.stream_wait(dev, side, None)          # z_vals come from the samplers on this stream
-            with _hip.on_device(dev):
-                _hip.check(lib.eslam_scatter_prep(arr, _hip.make_bound(bound6), _hip.ptr(rays_o), _hip.ptr(rays_d),
-                                                  _hip.ptr(z_vals), R, S, _hip.ptr(order), _hip.ptr(records),
-                                                  ctypes.c_void_p(side.cuda_stream)), "eslam_scatter_prep")
-            records.record_stream(side)
-            for t in (rays_o, rays_d, z_vals):
-                t.record_stream(side)
         with _hip.on_device(dev):
             if fl is None:
                 _hip.check(lib.eslam_render_fwd(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(rays_o),
@@ -360,14 +427,13 @@ class RenderFn(torch.autograd.Function):
                                                      _take_rng_bump(dev), _hip.stream_handle(dev)), "eslam_render_fwd_loss")
                 ctx.lossctx = st
         if order_in is not None and side is not None:
-            # join the side stream (ray order, scatter records) BEHIND the forward kernel: the work beside it has overlapped,
+            # join the side stream (ray order, gradient clear) BEHIND the forward kernel: the work beside it has overlapped,
             # and no fork is left dangling if this forward is never followed by a backward (or sits in a graph of its own)
             _hip.stream_wait(dev, None, side)
             side = None
         if needs:
             ctx.bound6 = bound6
             ctx.order_stream = None
-            ctx.records = records
             ctx.save_for_backward(rays_o, rays_d, z_vals, sdf, raw_rgb, feat, order, beta, depth, rgb, *planes, *params)
         if fl is not None:
             return depth, rgb, sdf, fl.value.detach()     # an alias: the state must not hold the output object itself
@@ -419,8 +485,6 @@ class RenderFn(torch.autograd.Function):
         ws = torch.empty(lib.eslam_bwd_workspace_bytes(R * S), dtype=torch.uint8, device=dev)
         g_depth, g_rgb, g_sdf = _c(g_depth), _c(g_rgb), _c(g_sdf)
         fl = ctx.lossctx                 # a _LossState
-        records = getattr(ctx, "records", None)
-        ctx.records = None
         with _hip.on_device(dev):
             if fl is not None and g_loss is not None:
                 # the loss's gradients are formed inside the backward kernel from the set sizes in acc (a ray-sharded caller
@@ -433,13 +497,13 @@ class RenderFn(torch.autograd.Function):
                     _hip.ptr(fl.gt_depth), _hip.ptr(fl.gt_color), fl.truncation, w5, _hip.ptr(fl.ray_mask),
                     _hip.ptr(fl.acc if fl.acc_global is None else fl.acc_global), _hip.ptr(up), _hip.ptr(fl.value) if fl.rewrite_value else None, _hip.ptr(g_depth),
                     _hip.ptr(g_rgb), _hip.ptr(g_sdf), _hip.ptr(g_dec), _hip.ptr(g_beta), _hip.ptr(g_ro), _hip.ptr(g_rd),
-                    _hip.ptr(order), _hip.ptr(records), _hip.ptr(ws), _hip.stream_handle(dev)), "eslam_render_bwd_loss")
+                    _hip.ptr(order), _hip.ptr(ws), _hip.stream_handle(dev)), "eslam_render_bwd_loss")
             else:
                 _hip.check(lib.eslam_render_bwd(arr, ctypes.byref(dec), _hip.make_bound(ctx.bound6), _hip.ptr(rays_o),
                                                 _hip.ptr(rays_d), _hip.ptr(z_vals), R, S, _hip.ptr(sdf), _hip.ptr(raw_rgb),
                                                 _hip.ptr(feat), _hip.ptr(g_depth), _hip.ptr(g_rgb), _hip.ptr(g_sdf),
                                                 _hip.ptr(g_dec), _hip.ptr(g_beta), _hip.ptr(g_ro), _hip.ptr(g_rd),
-                                                _hip.ptr(order), _hip.ptr(records), _hip.ptr(ws), _hip.stream_handle(dev)),
+                                                _hip.ptr(order), _hip.ptr(ws), _hip.stream_handle(dev)),
                            "eslam_render_bwd")
         if sink is not None:
             # the data-parallel caller owns .grad assignment (FlatGrads.assign): hand autograd nothing to accumulate

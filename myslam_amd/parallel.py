@@ -243,8 +243,9 @@ class ShardedMapper:
         wl = self.wl
         for p in self.params:
             p.grad = None
-        depth, color, sdf, z, pre = wl.renderer.render_batch_ray_with_loss(
-            wl.planes, wl.decoders, wl.rays_d, wl.rays_o, wl.device, wl.truncation, wl.gt_depth, wl.gt_color, self.weights)
+        with ops.keep_layout():                    # the backward scatters into the flat buffer's views: the planes' own strides
+            depth, color, sdf, z, pre = wl.renderer.render_batch_ray_with_loss(
+                wl.planes, wl.decoders, wl.rays_d, wl.rays_o, wl.device, wl.truncation, wl.gt_depth, wl.gt_color, self.weights)
         pre.acc_global = self._gacc                # RenderFn.backward scales by these, not by this rank's own set sizes
         self._pre = pre
         ops.join_ray_order(wl.device)              # forward and backward are separate graphs: join the fork in this one

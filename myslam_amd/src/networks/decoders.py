@@ -36,6 +36,7 @@ class Decoders(nn.Module):
         # self.bound is set from outside (reference ESLAM.py:173), a CPU [3,2] tensor
 
     def _decode(self, p_flat, bound6, all_planes):
+        all_planes = ops.planes_for_kernels(all_planes, p_flat.shape[0])
         flat_planes = [p for grp in all_planes for p in grp]
         dummy_beta = ops.beta_tensor(10, p_flat.device)
         return ops.DecodeFn.apply(p_flat, bound6, dummy_beta, *flat_planes, *ops.decoder_params(self))
@@ -49,7 +50,7 @@ class Decoders(nn.Module):
         wants = p.requires_grad or any(t.requires_grad for t in self.parameters()) or \
             any(t.requires_grad for grp in all_planes[:3] for t in grp)
         if not (torch.is_grad_enabled() and wants):
-            return ops.decode_sdf_only(p, _UNIT_BOUND, all_planes, self)
+            return ops.decode_sdf_only(p, _UNIT_BOUND, ops.planes_for_kernels(all_planes, p.shape[0]), self)
         return self._decode(p, _UNIT_BOUND, all_planes)[:, 3]
 
     def get_raw_rgb(self, p_nor, all_planes):

@@ -31,6 +31,8 @@ class Renderer(object):
         if n_rays == 0:
             e = rays_o.new_empty
             return e(0), e(0, 3), e(0, S), e(0, S)
+        # planes in the reference's NCHW layout: per-call channels-last scratch copies (gradients flow back through them)
+        all_planes = ops.planes_for_kernels(all_planes, n_rays * S)
         flat_planes = [p for grp in all_planes for p in grp]
         # training calls get a direction-sorted ray order (better L2 locality forward, bundling for the scatter); it only
         # depends on the rays, so it runs on a side stream next to the samplers

@@ -114,14 +114,53 @@ def test_render_fwd_bwd_matches_reference_fixture(case):
     check_against_fixture(fx, run_hip(fx))
 
 
+@pytest.mark.parametrize("relayout", [True, False])
 @pytest.mark.parametrize("case", ["room0_200x32", "room0_200x40_zero15", "room0_200x40_trained_zero15"])
-def test_render_nchw_planes(case):
-    """Planes exactly as the reference allocates them (NCHW-contiguous) go through the strided kernels."""
+def test_render_nchw_planes(case, relayout, monkeypatch):
+    """Planes exactly as the reference allocates them (NCHW-contiguous, ESLAM.py:199-210).  relayout: per-call channels-last
+    scratch copies in front of the kernels and the gradients brought back to the planes' own strides behind them
+    (eslam_planes_relayout; the default from 4096 points up); otherwise the strided kernels read / scatter NCHW directly."""
+    from myslam_amd import ops
+    monkeypatch.setattr(ops, "_RELAYOUT_MIN_POINTS", 0 if relayout else -1)
     fx = hp.load(case)
     r = run_hip(fx, channels_last=False)
     check_against_fixture(fx, r)
     for p in hp.flat_planes(r["planes"]):
-        assert p.grad.stride() == p.stride()
+        assert p.grad.stride() == p.stride() and p.is_contiguous()
+
+
+def test_render_nchw_planes_bench_size_equals_channels_last():
+    """4096 x 64, trained-like state: NCHW planes through the layout change give the fixture's results, and plane gradients
+    equal to the channels-last run's up to the order of the float atomics."""
+    fx = hp.load("room0_4096x64_trained_zero10")
+    a = run_hip(fx, channels_last=False)
+    check_against_fixture(fx, a)
+    b = run_hip(fx, channels_last=True)
+    for pa, pb in zip(hp.flat_planes(a["planes"]), hp.flat_planes(b["planes"])):
+        assert pa.grad.stride() == pa.stride() and pa.is_contiguous()
+        assert hp.rel_err(pa.grad.cpu().numpy(), pb.grad.cpu().numpy()) <= 1e-5
+
+
+def test_planes_relayout_round_trip_and_errors():
+    """eslam_planes_relayout: NCHW -> channels-last -> NCHW is the identity bit for bit on odd shapes (tiles of 64 texels with
+    ragged ends), both fields; mixed directions and non-dense planes are refused."""
+    from myslam_amd import ops
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(3)
+    shapes = [(2, 2), (3, 67), (21, 27), (64, 1 + 64), (111, 164), (5, 13), (2, 64), (7, 9), (33, 31), (128, 2), (9, 7), (84, 111)]
+    src = [torch.randn(1, 32, h, w, device=dev, generator=g) for h, w in shapes]
+    _, cl = ops._flat_views(src, torch.channels_last)
+    ops._relayout(src, cl, 0)
+    for a, b in zip(src, cl):
+        assert b.is_contiguous(memory_format=torch.channels_last) and torch.equal(a, b)
+    _, back = ops._flat_views(src, torch.contiguous_format)
+    ops._relayout(cl, back, 1)
+    for a, b in zip(src, back):
+        assert b.is_contiguous() and torch.equal(a, b)
+    with pytest.raises(RuntimeError, match="same way"):
+        ops._relayout([src[0]] + cl[1:], [cl[0]] + back[1:], 0)
+    with pytest.raises(RuntimeError, match="dense"):
+        ops._relayout(src, back, 0)
 
 
 @pytest.mark.parametrize("case", ["room0_200x32", "room0_200x40_zero15", "room0_200x40_tracking", "room0_200x40_trained_zero15"])
