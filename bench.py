@@ -10,10 +10,10 @@ render_batch_ray forward -> mapping loss -> backward to the 12 planes and the de
   N = 1 (default)   BASELINE.json configs[1]: synthetic Replica room0, 4096 rays x 64 samples (56 stratified + 8 surface).
   N > 1 (default)   BASELINE.json configs[3], the split north_star names: ONE synthetic ScanNet scene0000 batch of
                     8192 rays x 96 samples (10 % depth-less rays), identical on every rank, each rank renders its
-                    contiguous 1/N slice (parallel.shard_slice) and the ranks exchange the loss's set sizes + touched
-                    texels (one int32 all-reduce) and the gradients (block-sparse all-reduce) over RCCL / xGMI:
+                    contiguous 1/N slice (parallel.shard_slice); the loss's global set sizes and the texels the batch can
+                    touch are computed redundantly on every rank, ONE all-reduce of [tail | those texels' gradients] over RCCL / xGMI:
                     "scaling": "strong".  --strong runs the same workload at N = 1 (the unsharded step through the same
-                    code); --weak gives every rank its own 4096 x 64 room0 batch instead ("scaling": "weak").
+                    code); --weak lets the room0 batch grow with the job instead, 4096 x 64 per rank ("scaling": "weak").
 
 value = ray.samples/s of the whole job = (rays of the job) * S / t_step, t_step = max over ranks of (wall time of K steps)/K.
 roofline = per kernel, against the ceiling that actually bounds it (/opt/skills/guides/MI355X_MICROARCH.md): the forward
@@ -340,9 +340,12 @@ def run():
     if strong:       # ONE batch, the same on every rank; this rank keeps its contiguous slice
         wl = harness.make_workload(cfg["scene"], cfg["rays"], cfg["n_strat"], cfg["n_imp"], device=dev,
                                    zero_frac=cfg["zero_frac"], seed=0, shard=(rank, world))
+    elif world > 1:  # --weak: the batch grows with the job (4096 rays per rank), every rank still draws all of it and keeps its slice
+        wl = harness.make_workload(cfg["scene"], cfg["rays"] * world, cfg["n_strat"], cfg["n_imp"], device=dev,
+                                   zero_frac=cfg["zero_frac"], seed=0, shard=(rank, world))
     else:
         wl = harness.make_workload(cfg["scene"], cfg["rays"], cfg["n_strat"], cfg["n_imp"], device=dev,
-                                   zero_frac=cfg["zero_frac"], seed=rank)
+                                   zero_frac=cfg["zero_frac"], seed=0)
     mapper = None
     if world > 1 or strong or os.environ.get("BENCH_FORCE_DP") == "1":   # BENCH_FORCE_DP: the sharded step on one rank
         from myslam_amd.parallel import ShardedMapper
@@ -359,7 +362,7 @@ def run():
     graphed = False
     if not args.no_graph:
         # capture the iteration into hipGraphs: the step is launch-bound when issued from Python.  With a mapper the
-        # collective-free phases of the sharded step are captured separately and the two all-reduces stay eager.
+        # collective-free halves of the sharded step are captured separately and the one all-reduce stays eager.
         try:
             if mapper is not None:
                 mapper.capture()
@@ -415,13 +418,15 @@ def run():
                        "plane_bytes": wl.scene.plane_bytes, "planes_layout": "channels_last",
                        "parallelism": f"ray-sharded dp{world}" if mapper is not None else "single GPU",
                        "gradient_exchange": None if mapper is None else
-                       ("block-sparse: union of touched texels (ESLAM_DP_COMPACT=0 for dense)" if mapper.compact
+                       ("[dense tail | texels the batch's rays can touch] of the flat gradient buffer, the list built on the device "
+                        "from ray geometry (ESLAM_DP_COMPACT=0 for a dense all-reduce)" if mapper.compact
                         else "dense all-reduce of the flat gradient buffer"),
-                       "collectives_per_step": None if mapper is None else 2,
+                       "collectives_per_step": None if mapper is None else 1,
                        "loss": "sums formed in the forward kernel's epilogue (eslam_render_fwd_loss), gradients formed inside "
                                "the backward kernel (eslam_render_bwd_loss)" +
-                               ("; set sizes made global by the int32 sync all-reduce" if mapper is not None else ""),
-                       "launch": ("hipGraph replay of the captured iteration" + (" (2 graphs, collectives eager)" if mapper is not None
+                               ("; global set sizes computed redundantly on every rank from the whole batch (eslam_loss_set_sizes)"
+                                if mapper is not None else ""),
+                       "launch": ("hipGraph replay of the captured iteration" + (" (2 graphs, the one all-reduce eager between them)" if mapper is not None
                                                                                               else ""))
                        if graphed else "eager launches from Python"},
             # (ray-sharded runs: this rank's kernels on this rank's shard; the PMC bytes are collected for the N = 1 workload only)

@@ -118,11 +118,14 @@ int eslam_sample_z_all(const eslam_plane_t* planes, const eslam_decoders_t* dec,
  * stream injects it through eslam_sample_z_all): U = hash(seed, step, stream, element) / 2^24 in [0,1), with
  * step = *rng_state (device memory; NULL = 0).  perturb = 0 leaves the samples un-jittered (Renderer.perturb False);
  * the importance draw is random either way.  Pass the same rng_state as `rng_bump` to the eslam_render_fwd* call that
- * consumes z_vals: it advances the step, so a replayed hipGraph draws fresh numbers without an extra launch.        */
+ * consumes z_vals: it advances the step, so a replayed hipGraph draws fresh numbers without an extra launch.
+ * ray_offset: index of this call's ray 0 in the iteration's whole batch (0 for an unsharded call).  The numbers are keyed
+ * on the GLOBAL ray index ray_offset + i, so the ranks of a ray-sharded iteration - same seed, same step - draw exactly what
+ * the unsharded batch draws: its z_vals, and with them the loss's set sizes, do not depend on the world size.            */
 int eslam_sample_z_all_rng(const eslam_plane_t* planes, const eslam_decoders_t* dec, const float* bound6_host,
                            const float* rays_o, const float* rays_d, const float* gt_depth, int R, int n_strat, int n_imp,
                            double truncation, const float* t_free, const float* t_surf, int perturb, uint64_t seed,
-                           const uint32_t* rng_state, float* z_vals, eslam_stream_t stream);
+                           const uint32_t* rng_state, int64_t ray_offset, float* z_vals, eslam_stream_t stream);
 
 /* K5-K7 forward.  Replaces src/utils/Renderer.py:136-147 + src/networks/decoders.py:64-146 +
  * src/common.py:204-218:  pts = o + d z -> normalise -> tri-plane bilinear gather (border, align_corners) ->
@@ -351,29 +354,6 @@ int eslam_loss_value(const float* depth, const float* rgb, const float* sdf, con
                      const float* weights5_host, const uint8_t* ray_mask, float* scratch, float* acc, float* loss,
                      eslam_stream_t stream);
 
-/* Block-sparse exchange of the flat gradient buffer between ray-sharded ranks ("reducing only
- * touched tiles"; myslam_amd/parallel.py).  A block is 32 consecutive floats = one texel's channels in a channels_last
- * plane.  eslam_blocks_touched: touched[b] = 1 if block b of `flat` holds a non-zero.  After the ranks have agreed on the
- * union (an all-reduce(MAX) of `touched`, then idx = its non-zero positions, ascending): eslam_blocks_pack gathers
- * blocks idx[0..n_idx) and the dense `tail` (decoder gradients) into buf [n_idx*32 + n_tail]; eslam_blocks_unpack
- * writes the all-reduced buf back.  flat and buf 16-byte aligned.                                                   */
-int eslam_blocks_touched(const float* flat, int64_t n_blocks, uint8_t* touched, eslam_stream_t stream);
-/* The same bitmap from the sample positions instead of the gradients - available right after the forward pass, so the
- * ranks can agree on the union while the backward pass runs.  channels_last planes only (one block = one texel);
- * block_base_host[12] = index of each plane's first block in the flat buffer; touched [n_blocks] is cleared here.
- * Marks every texel eslam_render_bwd will add to (a superset of the non-zero blocks).                           */
-int eslam_mark_touched(const eslam_plane_t* planes, const float* bound6_host, const float* rays_o, const float* rays_d,
-                       const float* z_vals, int R, int S, const int64_t* block_base_host, int64_t n_blocks,
-                       uint8_t* touched, eslam_stream_t stream);
-int eslam_blocks_pack(const float* flat, const int64_t* idx, int64_t n_idx, const float* tail, int64_t n_tail, float* buf,
-                      eslam_stream_t stream);
-int eslam_blocks_unpack(float* flat, const int64_t* idx, int64_t n_idx, float* tail, int64_t n_tail, const float* buf,
-                        eslam_stream_t stream);
-/* Sparse clear of the flat gradient buffer: zero the 128-byte blocks idx [n_idx] (the union exchanged in the previous
- * iteration - every other block of the plane region is still zero) and the dense tail [n_tail] - 1.6-4.5 MB of stores
- * instead of a 27-70 MB fill.                                                                               */
-int eslam_blocks_zero(float* flat, const int64_t* idx, int64_t n_idx, float* tail, int64_t n_tail, eslam_stream_t stream);
-
 /* Per-kernel device timing for bench.py's roofline line (HIP events recorded on the launch stream around each
  * kernel while enabled; adds nothing to the launch path when disabled).  Usage: enable(1); run one iteration;
  * synchronise the stream; read(ms) -> elapsed milliseconds of the LAST launch of each kernel, -1 if it did not run. */
@@ -382,17 +362,61 @@ int eslam_profile_enable(int on);
 int eslam_profile_read(float* ms_out);
 const char* eslam_profile_name(int kernel_id);
 
-/* The one collective between the forward and the backward pass of a ray-sharded mapping iteration (new: the reference is
- * single-GPU).  eslam_shard_sync_pack writes this rank's five loss set sizes (from acc
- * [ESLAM_LOSS_ACC], src/Mapper.py:136-140,343,346 take means over them) and its touched-texel bytes (eslam_mark_touched;
- * n_blocks may be 0) into out [eslam_shard_sync_words(n_blocks)] int32, six texels per word as 4-bit counts; the caller
- * all-reduces that buffer with SUM (exact in integers, any backend, world <= 15); eslam_shard_sync_unpack then writes
- * acc_global [ESLAM_LOSS_ACC] = acc_local with the five set sizes replaced by the global ones (what
- * eslam_render_bwd_loss scales its gradients with) and touched [n_blocks] = the union over ranks.             */
-int64_t eslam_shard_sync_words(int64_t n_blocks);
-int eslam_shard_sync_pack(const float* acc, const uint8_t* touched, int64_t n_blocks, int32_t* out, eslam_stream_t stream);
-int eslam_shard_sync_unpack(const int32_t* in, int64_t n_blocks, const float* acc_local, float* acc_global,
-                            uint8_t* touched, eslam_stream_t stream);
+/* Ray-sharded mapping iteration WITHOUT a collective between forward and backward (round 3; SURVEY.md section 8(e):
+ * "compute them redundantly on every rank").  Every rank holds the iteration's whole batch of rays (same get_samples draw,
+ * src/Mapper.py:318-319) and renders its slice; what the backward needs from the other ranks' rays it computes itself:
+ *
+ * eslam_loss_set_sizes: the five set sizes the mapping loss takes its means over (src/Mapper.py:136-140,343,346) for all R
+ *   rays of the batch, without rendering them - they depend on gt_depth, ray_mask and the depth-guided z_vals of the rays
+ *   with depth only (src/utils/Renderer.py:85-105), which the kernel replays in LDS with the sampler's own arithmetic and
+ *   random numbers (t_rand [R,S] injected, or NULL = the in-kernel numbers of eslam_sample_z_all_rng for seed / rng_state /
+ *   global ray index).  acc_out [ESLAM_LOSS_ACC]: the count slots as floats, other slots 0 - hand it to
+ *   eslam_render_bwd_loss as `acc`.  scratch: 7 x 32 uint32, zeroed once by the caller, left zeroed.
+ * eslam_mark_rays: touched [n_blocks] (cleared here) <- 1 for every texel that CAN receive gradient from the batch's rays,
+ *   from ray geometry alone: the samples of a ray with depth d lie in [min(0, d - 1.5 tau), max(1.2 d, d + 1.5 tau)], those of
+ *   a depth-less ray in [0, AABB exit + 0.01] (Renderer.py:96-100,114-134); the segment is rasterised conservatively into
+ *   each plane.  A superset of the texels the ranks' backward passes add to, identical on every rank, known before anything
+ *   is sampled.  channels_last planes only (one block = one texel's 32 channels = 128 bytes of the flat gradient buffer);
+ *   block_base_host[12] = index of each plane's first block in that buffer.
+ * eslam_blocks_compact: idx [n_blocks capacity] <- ascending indices of the non-zero bytes of touched; meta[0] <- their
+ *   number, meta[1] += 1 (a stamp: the host compares it with its own count of launches before it sizes the all-reduce).
+ *   host_meta_dev (optional): the device address of two int32 of pinned host memory (eslam_host_meta_alloc) that receive
+ *   the same two words straight from the kernel - no copy node.  clear_touched: zero the bytes behind the read, so that the
+ *   next iteration's marking needs no memset.  scratch: eslam_blocks_compact_scratch_words(n_blocks) uint32, zeroed once.
+ * eslam_shard_prologue: the clear of the previous iteration's gradients (eslam_blocks_zero_dev; clear_flat NULL = none), the
+ *   set sizes (eslam_loss_set_sizes, in-kernel random numbers) and the marking (eslam_mark_rays WITHOUT its memset: touched
+ *   must be clean - eslam_blocks_compact(clear_touched = 1) leaves it so; mark_planes NULL = none) as ONE launch: a replayed
+ *   hipGraph pays ~3 us per node, and this work sits beside the sampler and the forward kernel.
+ * eslam_blocks_pack_dev / _unpack_dev / _zero_dev: gather the listed blocks of `flat` and the dense `tail` (decoder / beta /
+ *   pose gradients, loss sums) into buf / write the all-reduced buf back / zero them, with the list's length read on the
+ *   device (meta[0]) and the dense tail FIRST: buf = [tail_pad floats (n_tail used, rest 0; tail_pad % 4 == 0) | 32 floats per
+ *   listed block], so that the all-reduce covers buf[0 : tail_pad + 32 meta[0]] of a fixed-capacity buffer.  step_bump
+ *   (pack, optional): a device counter the launch increments - a ray-sharded iteration keeps its random-number step there
+ *   (rng_state of eslam_sample_z_all_rng and eslam_shard_prologue, which read it on two streams) and advances it with its
+ *   last launch instead of through eslam_render_fwd*'s rng_bump.                                                       */
+int eslam_loss_set_sizes(const float* gt_depth, const uint8_t* ray_mask, int R, int n_strat, int n_imp, double truncation,
+                         const float* t_free, const float* t_surf, const float* t_rand, int perturb, uint64_t seed,
+                         const uint32_t* rng_state, uint32_t* scratch, float* acc_out, eslam_stream_t stream);
+int eslam_mark_rays(const eslam_plane_t* planes, const float* bound6_host, const float* rays_o, const float* rays_d,
+                    const float* gt_depth, int R, double truncation, const int64_t* block_base_host, int64_t n_blocks,
+                    uint8_t* touched, eslam_stream_t stream);
+int64_t eslam_blocks_compact_scratch_words(int64_t n_blocks);
+int eslam_blocks_compact(uint8_t* touched, int64_t n_blocks, uint32_t* scratch, int32_t* idx, int32_t* meta,
+                         int32_t* host_meta_dev, int clear_touched, eslam_stream_t stream);
+int eslam_host_meta_alloc(void** host_ptr, void** dev_ptr);
+int eslam_host_meta_free(void* host_ptr);
+int eslam_shard_prologue(float* clear_flat, const int32_t* clear_idx, const int32_t* clear_meta, int64_t clear_capacity,
+                         float* clear_tail, int64_t clear_n_tail, const float* rays_o, const float* rays_d,
+                         const float* gt_depth, const uint8_t* ray_mask, int R, int n_strat, int n_imp, double truncation,
+                         const float* t_free, const float* t_surf, int perturb, uint64_t seed, const uint32_t* rng_state,
+                         uint32_t* sizes_scratch, float* acc_out, const eslam_plane_t* mark_planes, const float* bound6_host,
+                         const int64_t* block_base_host, int64_t n_blocks, uint8_t* touched, eslam_stream_t stream);
+int eslam_blocks_pack_dev(const float* flat, const int32_t* idx, const int32_t* meta, int64_t capacity, const float* tail,
+                          int64_t n_tail, int64_t tail_pad, float* buf, uint32_t* step_bump, eslam_stream_t stream);
+int eslam_blocks_unpack_dev(float* flat, const int32_t* idx, const int32_t* meta, int64_t capacity, float* tail,
+                            int64_t n_tail, int64_t tail_pad, const float* buf, eslam_stream_t stream);
+int eslam_blocks_zero_dev(float* flat, const int32_t* idx, const int32_t* meta, int64_t capacity, float* tail, int64_t n_tail,
+                          eslam_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -49,7 +49,18 @@ SIGNATURES = {
     "eslam_sample_z": (_i, [_vp, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp]),
     "eslam_importance_z": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "eslam_sample_z_all": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "eslam_sample_z_all_rng": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _i, _d, _vp, _vp, _i, ctypes.c_uint64, _vp, _vp, _vp]),
+    "eslam_sample_z_all_rng": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _i, _d, _vp, _vp, _i, ctypes.c_uint64, _vp, _i64, _vp, _vp]),
+    "eslam_loss_set_sizes": (_i, [_vp, _vp, _i, _i, _i, _d, _vp, _vp, _vp, _i, ctypes.c_uint64, _vp, _vp, _vp, _vp]),
+    "eslam_mark_rays": (_i, [_PP, _BP, _vp, _vp, _vp, _i, _d, _vp, _i64, _vp, _vp]),
+    "eslam_blocks_compact_scratch_words": (_i64, [_i64]),
+    "eslam_blocks_compact": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _i, _vp]),
+    "eslam_host_meta_alloc": (_i, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]),
+    "eslam_host_meta_free": (_i, [_vp]),
+    "eslam_shard_prologue": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _d, _vp, _vp, _i, ctypes.c_uint64,
+                                  _vp, _vp, _vp, _PP, _BP, _vp, _i64, _vp, _vp]),
+    "eslam_blocks_pack_dev": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "eslam_blocks_unpack_dev": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp]),
+    "eslam_blocks_zero_dev": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp]),
     "eslam_render_fwd": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "eslam_render_fwd_loss": (_i, [_PP, _DP, _BP, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _BP, _vp,
                                    _vp, _vp, _vp, _vp, _vp]),
@@ -82,14 +93,6 @@ SIGNATURES = {
     "eslam_pose_to_c2w_bwd": (_i, [_vp, _vp, _i, _vp, _vp]),
     "eslam_tracking_mask": (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp]),
     "eslam_keep_best": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
-    "eslam_mark_touched": (_i, [_PP, _BP, _vp, _vp, _vp, _i, _i, _vp, _i64, _vp, _vp]),
-    "eslam_blocks_touched": (_i, [_vp, _i64, _vp, _vp]),
-    "eslam_blocks_pack": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
-    "eslam_blocks_unpack": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
-    "eslam_blocks_zero": (_i, [_vp, _vp, _i64, _vp, _i64, _vp]),
-    "eslam_shard_sync_words": (_i64, [_i64]),
-    "eslam_shard_sync_pack": (_i, [_vp, _vp, _i64, _vp, _vp]),
-    "eslam_shard_sync_unpack": (_i, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "eslam_keyframe_overlap": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _f, _f, _f, _f, _i, _vp, _vp]),
 }
 

@@ -154,170 +154,3 @@ extern "C" int eslam_keep_best(const float* loss, const float* pose, int n, floa
     hipLaunchKernelGGL(keep_best_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, loss, pose, n, best, best_pose);
     return eslam_check_launch("keep_best_kernel");
 }
-
-// ---------------------------------------------------------------------------------------------------------
-// Block-sparse gradient exchange of the ray-sharded mapper (myslam_amd/parallel.py FlatGrads.all_reduce_compact):
-// which 128-byte blocks (one texel's 32 channels in a channels_last plane) of the flat gradient buffer are non-zero,
-// and gather / scatter of the blocks every rank agreed to exchange.  8 lanes x float4 per block.
-// ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void blocks_touched_kernel(const float* __restrict__ flat, int64_t n_blocks,
-                                                             uint8_t* __restrict__ touched) {
-    const int sub = threadIdx.x & 7;
-    for (int64_t b = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); b < n_blocks; b += (int64_t)gridDim.x * 32) {
-        const float4_t v = *(const float4_t*)(flat + b * 32 + sub * 4);
-        int nz = (v[0] != 0.0f) | (v[1] != 0.0f) | (v[2] != 0.0f) | (v[3] != 0.0f);
-        nz |= __shfl_xor(nz, 1, WAVE);
-        nz |= __shfl_xor(nz, 2, WAVE);
-        nz |= __shfl_xor(nz, 4, WAVE);
-        if (sub == 0) touched[b] = (uint8_t)nz;
-    }
-}
-
-// MODE 0: gather blocks into buf; 1: scatter buf back; 2: zero the listed blocks and the tail (sparse clear of a gradient
-// buffer whose non-zero blocks are known: the union the ranks exchanged in the previous iteration)
-template <int MODE>
-__global__ __launch_bounds__(256) void blocks_move_kernel(float* __restrict__ flat, const int64_t* __restrict__ idx,
-                                                          int64_t n_idx, float* __restrict__ tail, int64_t n_tail,
-                                                          float* __restrict__ buf) {
-    const int sub = threadIdx.x & 7;
-    const int64_t stride = (int64_t)gridDim.x * 32;
-    for (int64_t i = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); i < n_idx; i += stride) {
-        float4_t* a = (float4_t*)(flat + idx[i] * 32 + sub * 4);
-        float4_t* b = (float4_t*)(buf + i * 32 + sub * 4);
-        if (MODE == 0) *b = *a;
-        else if (MODE == 1) *a = *b;
-        else *a = (float4_t){0.f, 0.f, 0.f, 0.f};
-    }
-    float* tbuf = buf + n_idx * 32;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_tail; i += (int64_t)gridDim.x * 256) {
-        if (MODE == 0) tbuf[i] = tail[i];
-        else if (MODE == 1) tail[i] = tbuf[i];
-        else tail[i] = 0.0f;
-    }
-}
-
-extern "C" int eslam_blocks_touched(const float* flat, int64_t n_blocks, uint8_t* touched, eslam_stream_t stream) {
-    if (n_blocks <= 0) return 0;
-    if (!flat || !touched || ((uintptr_t)flat & 15)) {
-        eslam_set_error("eslam_blocks_touched: null or unaligned argument");
-        return 1;
-    }
-    const int64_t want = (n_blocks + 31) / 32;
-    hipLaunchKernelGGL(blocks_touched_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0,
-                       (hipStream_t)stream, flat, n_blocks, touched);
-    return eslam_check_launch("blocks_touched_kernel");
-}
-
-static int blocks_move(int mode, float* flat, const int64_t* idx, int64_t n_idx, float* tail, int64_t n_tail, float* buf,
-                       eslam_stream_t stream) {
-    if (n_idx < 0 || n_tail < 0) {
-        eslam_set_error("eslam_blocks_pack/unpack: negative size");
-        return 1;
-    }
-    if (n_idx == 0 && n_tail == 0) return 0;
-    if ((mode != 2 && !buf) || (n_idx > 0 && (!flat || !idx)) || (n_tail > 0 && !tail) || ((uintptr_t)flat & 15) || ((uintptr_t)buf & 15)) {
-        eslam_set_error("eslam_blocks_pack/unpack: null or unaligned argument");
-        return 1;
-    }
-    const int64_t want = (n_idx + 31) / 32 > (n_tail + 255) / 256 ? (n_idx + 31) / 32 : (n_tail + 255) / 256;
-    const dim3 grid((unsigned)(want < 4096 ? (want > 0 ? want : 1) : 4096));
-    if (mode == 0)
-        hipLaunchKernelGGL(blocks_move_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, flat, idx, n_idx, tail,
-                           n_tail, buf);
-    else if (mode == 1)
-        hipLaunchKernelGGL(blocks_move_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, flat, idx, n_idx, tail,
-                           n_tail, buf);
-    else
-        hipLaunchKernelGGL(blocks_move_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, flat, idx, n_idx, tail,
-                           n_tail, buf);
-    return eslam_check_launch("blocks_move_kernel");
-}
-
-extern "C" int eslam_blocks_pack(const float* flat, const int64_t* idx, int64_t n_idx, const float* tail, int64_t n_tail,
-                                 float* buf, eslam_stream_t stream) {
-    return blocks_move(0, (float*)flat, idx, n_idx, (float*)tail, n_tail, buf, stream);
-}
-
-extern "C" int eslam_blocks_unpack(float* flat, const int64_t* idx, int64_t n_idx, float* tail, int64_t n_tail,
-                                   const float* buf, eslam_stream_t stream) {
-    return blocks_move(1, flat, idx, n_idx, tail, n_tail, (float*)buf, stream);
-}
-
-extern "C" int eslam_blocks_zero(float* flat, const int64_t* idx, int64_t n_idx, float* tail, int64_t n_tail,
-                                 eslam_stream_t stream) {
-    return blocks_move(2, flat, idx, n_idx, tail, n_tail, nullptr, stream);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// ONE collective between the forward and the backward pass of a ray-sharded mapping iteration (myslam_amd/parallel.py):
-// the five set sizes of the loss (src/Mapper.py:136-140,343,346 take means over them) and the union of texels the ranks'
-// backward passes will touch travel in one int32 buffer that is all-reduced with SUM - exact, order-independent, and
-// supported by every backend (round 1 needed a 16-float SUM and a byte MAX, two latency-bound collectives).
-//   word 0..4   N_front, N_center, N_tail, N_depth, N_color of this rank's rays (integers; the loss SUMS are not needed
-//               before the backward pass and ride in the gradient exchange instead)
-//   word 8 + k  six texels per word, 4 bits each: (touched[6k+i] != 0) << 4i.  After the SUM a nibble holds the number of
-//               ranks that touch the texel (world <= 15, no carry into the next nibble).
-// ---------------------------------------------------------------------------------------------------------
-#include "eslam_loss_final.h"
-#define SYNC_HEAD 8
-
-__global__ __launch_bounds__(256) void shard_sync_pack_kernel(const float* __restrict__ acc, const uint8_t* __restrict__ touched,
-                                                              int64_t n, int32_t* __restrict__ out) {
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w == 0) {
-        out[0] = (int32_t)acc[A_N_FRONT]; out[1] = (int32_t)acc[A_N_CENTER]; out[2] = (int32_t)acc[A_N_TAIL];
-        out[3] = (int32_t)acc[A_N_DEPTH]; out[4] = (int32_t)acc[A_N_COLOR]; out[5] = out[6] = out[7] = 0;
-    }
-    if (w * 6 >= n) return;
-    int32_t v = 0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-        if (w * 6 + i < n && touched[w * 6 + i]) v |= 1 << (4 * i);
-    out[SYNC_HEAD + w] = v;
-}
-
-__global__ __launch_bounds__(256) void shard_sync_unpack_kernel(const int32_t* __restrict__ in, int64_t n,
-                                                                const float* __restrict__ acc_local,
-                                                                float* __restrict__ acc_global, uint8_t* __restrict__ touched) {
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w < ESLAM_LOSS_ACC) {
-        float v = acc_local[w];
-        if (w == A_N_FRONT) v = (float)in[0];
-        else if (w == A_N_CENTER) v = (float)in[1];
-        else if (w == A_N_TAIL) v = (float)in[2];
-        else if (w == A_N_DEPTH) v = (float)in[3];
-        else if (w == A_N_COLOR) v = (float)in[4];
-        acc_global[w] = v;
-    }
-    if (w * 6 >= n) return;
-    const int32_t v = in[SYNC_HEAD + w];
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-        if (w * 6 + i < n) touched[w * 6 + i] = ((v >> (4 * i)) & 15) ? 1 : 0;
-}
-
-extern "C" int64_t eslam_shard_sync_words(int64_t n_blocks) { return n_blocks < 0 ? -1 : SYNC_HEAD + (n_blocks + 5) / 6; }
-
-extern "C" int eslam_shard_sync_pack(const float* acc, const uint8_t* touched, int64_t n_blocks, int32_t* out,
-                                     eslam_stream_t stream) {
-    if (!acc || !out || n_blocks < 0 || (n_blocks > 0 && !touched)) {
-        eslam_set_error("eslam_shard_sync_pack: null argument");
-        return 1;
-    }
-    const int64_t words = (n_blocks + 5) / 6;
-    hipLaunchKernelGGL(shard_sync_pack_kernel, dim3((unsigned)((words > 0 ? words : 1) + 255) / 256), dim3(256), 0,
-                       (hipStream_t)stream, acc, touched, n_blocks, out);
-    return eslam_check_launch("shard_sync_pack_kernel");
-}
-
-extern "C" int eslam_shard_sync_unpack(const int32_t* in, int64_t n_blocks, const float* acc_local, float* acc_global,
-                                       uint8_t* touched, eslam_stream_t stream) {
-    if (!in || !acc_local || !acc_global || n_blocks < 0 || (n_blocks > 0 && !touched)) {
-        eslam_set_error("eslam_shard_sync_unpack: null argument");
-        return 1;
-    }
-    const int64_t words = (n_blocks + 5) / 6;
-    hipLaunchKernelGGL(shard_sync_unpack_kernel, dim3((unsigned)((words > 16 ? words : 16) + 255) / 256), dim3(256), 0,
-                       (hipStream_t)stream, in, n_blocks, acc_local, acc_global, touched);
-    return eslam_check_launch("shard_sync_unpack_kernel");
-}

@@ -452,29 +452,40 @@ __global__ __launch_bounds__(256, 2) void importance_z_kernel(const PlaneSet pla
 // scratch: 7 lines of 32 unsigned, zeroed once by the caller; left zeroed.
 // ---------------------------------------------------------------------------------------------------------
 #include "eslam_loss_final.h"
-__global__ __launch_bounds__(256) void loss_set_sizes_kernel(const float* __restrict__ gt_depth, const uint8_t* __restrict__ ray_mask,
-                                                            int R, int n_strat, int n_imp, float c15, float c3,
-                                                            const float* __restrict__ t_free, const float* __restrict__ t_surf,
-                                                            const float* __restrict__ t_rand, const RngArg rng_arg, const Trunc tr,
-                                                            unsigned* __restrict__ scratch, float* __restrict__ acc_out) {
-    const Rng rng = make_rng(rng_arg);
+#include "eslam_shard_dev.h"
+struct SetSizesArgs {
+    const float* gt_depth;
+    const uint8_t* ray_mask;
+    int R, n_strat, n_imp;
+    float c15, c3;
+    const float* t_free;
+    const float* t_surf;
+    const float* t_rand;
+    RngArg rng;
+    Trunc tr;
+    unsigned* scratch;
+    float* acc_out;
+};
+// block `bid` of `nblocks` blocks of 256 threads (the ticket counts to nblocks)
+__device__ __forceinline__ void set_sizes_block(const SetSizesArgs& a, const int bid, const int nblocks) {
+    const Rng rng = make_rng(a.rng);
     __shared__ float zs_all[4][ESLAM_MAX_SAMPLES];
     __shared__ float zo_all[4][ESLAM_MAX_SAMPLES];
     __shared__ unsigned part[4][5];
     __shared__ unsigned ticket;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int S = n_strat + n_imp;
+    const int S = a.n_strat + a.n_imp;
     unsigned cnt[5] = {0u, 0u, 0u, 0u, 0u};                    // front, center, tail, depth, colour: this lane's share
-    for (int ray = blockIdx.x * 4 + wave; ray < R; ray += gridDim.x * 4) {
-        if (ray_mask && ray_mask[ray] == 0) continue;          // (uniform over the wave)
+    for (int ray = bid * 4 + wave; ray < a.R; ray += nblocks * 4) {
+        if (a.ray_mask && a.ray_mask[ray] == 0) continue;      // (uniform over the wave)
         if (lane == 0) cnt[4] += 3u;
-        const float d = gt_depth[ray];
+        const float d = a.gt_depth[ray];
         if (!(d > 0.0f)) continue;
         if (lane == 0) cnt[3] += 1u;
-        depth_guided_row(d, ray, n_strat, n_imp, c15, c3, t_free, t_surf, t_rand, zo_all[wave], zs_all[wave], lane, rng);
+        depth_guided_row(d, ray, a.n_strat, a.n_imp, a.c15, a.c3, a.t_free, a.t_surf, a.t_rand, zo_all[wave], zs_all[wave], lane, rng);
         WAVE_SYNC();
         for (int i = lane; i < S; i += WAVE) {
-            const int reg = sdf_region(zo_all[wave][i], d, tr);
+            const int reg = sdf_region(zo_all[wave][i], d, a.tr);
             if (reg < 3) cnt[reg] += 1u;
         }
         WAVE_SYNC();
@@ -488,14 +499,14 @@ __global__ __launch_bounds__(256) void loss_set_sizes_kernel(const float* __rest
     if (threadIdx.x < 5) {
         const unsigned tot = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
         if (tot) {
-            const unsigned old = atomicAdd(scratch + 32 * (threadIdx.x + 1), tot);
+            const unsigned old = atomicAdd(a.scratch + 32 * (threadIdx.x + 1), tot);
             asm volatile("" ::"v"(old));                       // performed once its result is back (as loss_finalize)
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) ticket = atomicAdd(scratch, 1u);
+    if (threadIdx.x == 0) ticket = atomicAdd(a.scratch, 1u);
     __syncthreads();
-    if (ticket != gridDim.x - 1) return;
+    if (ticket != (unsigned)nblocks - 1u) return;
     if (threadIdx.x < 16) {
         float v = 0.0f;
         int k = -1;
@@ -504,11 +515,26 @@ __global__ __launch_bounds__(256) void loss_set_sizes_kernel(const float* __rest
         else if (threadIdx.x == A_N_TAIL) k = 2;
         else if (threadIdx.x == A_N_DEPTH) k = 3;
         else if (threadIdx.x == A_N_COLOR) k = 4;
-        if (k >= 0) v = (float)atomicExch(scratch + 32 * (k + 1), 0u);
-        acc_out[threadIdx.x] = v;
+        if (k >= 0) v = (float)atomicExch(a.scratch + 32 * (k + 1), 0u);
+        a.acc_out[threadIdx.x] = v;
     }
     __syncthreads();
-    if (threadIdx.x == 0) atomicExch(scratch, 0u);
+    if (threadIdx.x == 0) atomicExch(a.scratch, 0u);
+}
+
+__global__ __launch_bounds__(256) void loss_set_sizes_kernel(const SetSizesArgs a) { set_sizes_block(a, blockIdx.x, gridDim.x); }
+
+// What a ray-sharded iteration does beside its sampler and forward kernel, as ONE launch (a replayed hipGraph pays ~3 us per
+// node whatever its size: the three pieces as launches of their own, with the memsets and copies around them, held the sampler
+// back by 40 us): blocks [0, n_clear) zero the previous iteration's marked texels + dense tail, the next n_sizes blocks form
+// the loss's global set sizes, the last n_mark blocks mark the texels the whole batch can touch.  The pieces are independent.
+__global__ __launch_bounds__(256) void shard_prologue_kernel(const ClearArgs c, const int n_clear, const SetSizesArgs s,
+                                                            const int n_sizes, const MarkArgs m, const int n_mark) {
+    int b = blockIdx.x;
+    if (b < n_clear) { clear_blocks_block(c, b, n_clear); return; }
+    b -= n_clear;
+    if (b < n_sizes) { set_sizes_block(s, b, n_sizes); return; }
+    mark_rays_block(m, b - n_sizes, n_mark);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -711,20 +737,19 @@ extern "C" int eslam_sample_z_all_rng(const eslam_plane_t* planes, const eslam_d
                              truncation, t_free, t_surf, nullptr, nullptr, nullptr, rng, z_vals, stream);
 }
 
-extern "C" int eslam_loss_set_sizes(const float* gt_depth, const uint8_t* ray_mask, int R, int n_strat, int n_imp,
-                                    double truncation, const float* t_free, const float* t_surf, const float* t_rand, int perturb,
-                                    uint64_t seed, const uint32_t* rng_state, uint32_t* scratch, float* acc_out,
-                                    eslam_stream_t stream) {
+static int fill_set_sizes_args(const char* who, const float* gt_depth, const uint8_t* ray_mask, int R, int n_strat, int n_imp,
+                               double truncation, const float* t_free, const float* t_surf, const float* t_rand, int perturb,
+                               uint64_t seed, const uint32_t* rng_state, uint32_t* scratch, float* acc_out, SetSizesArgs* a) {
     if (R <= 0 || n_strat < 1 || n_imp < 0 || n_strat + n_imp > ESLAM_MAX_SAMPLES) {
-        eslam_set_error("eslam_loss_set_sizes: R=%d n_strat=%d n_imp=%d unsupported", R, n_strat, n_imp);
+        eslam_set_error("%s: R=%d n_strat=%d n_imp=%d unsupported", who, R, n_strat, n_imp);
         return 1;
     }
     if (!gt_depth || !t_free || (n_imp > 0 && !t_surf) || !scratch || !acc_out) {
-        eslam_set_error("eslam_loss_set_sizes: null argument");
+        eslam_set_error("%s: null argument (set sizes)", who);
         return 1;
     }
     if ((int64_t)R * (n_strat + n_imp) >= ((int64_t)1 << 32)) {
-        eslam_set_error("eslam_loss_set_sizes: batch too large");
+        eslam_set_error("%s: batch too large", who);
         return 1;
     }
     RngArg rng = {};
@@ -732,9 +757,63 @@ extern "C" int eslam_loss_set_sizes(const float* gt_depth, const uint8_t* ray_ma
         rng.seed_lo = (uint32_t)seed; rng.seed_hi = (uint32_t)(seed >> 32); rng.state = rng_state; rng.on = 1;
         rng.perturb = perturb ? 1 : 0;
     }
+    a->gt_depth = gt_depth; a->ray_mask = ray_mask; a->R = R; a->n_strat = n_strat; a->n_imp = n_imp;
+    a->c15 = (float)(1.5 * truncation); a->c3 = (float)(3.0 * truncation);
+    a->t_free = t_free; a->t_surf = t_surf; a->t_rand = t_rand; a->rng = rng; a->tr = make_trunc(truncation);
+    a->scratch = scratch; a->acc_out = acc_out;
+    return 0;
+}
+
+extern "C" int eslam_loss_set_sizes(const float* gt_depth, const uint8_t* ray_mask, int R, int n_strat, int n_imp,
+                                    double truncation, const float* t_free, const float* t_surf, const float* t_rand, int perturb,
+                                    uint64_t seed, const uint32_t* rng_state, uint32_t* scratch, float* acc_out,
+                                    eslam_stream_t stream) {
+    SetSizesArgs a;
+    if (int rc = fill_set_sizes_args("eslam_loss_set_sizes", gt_depth, ray_mask, R, n_strat, n_imp, truncation, t_free, t_surf, t_rand,
+                                     perturb, seed, rng_state, scratch, acc_out, &a))
+        return rc;
     const int nwg = (R + 3) / 4 < 1024 ? (R + 3) / 4 : 1024;
-    hipLaunchKernelGGL(loss_set_sizes_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, gt_depth, ray_mask, R, n_strat, n_imp,
-                       (float)(1.5 * truncation), (float)(3.0 * truncation), t_free, t_surf, t_rand, rng, make_trunc(truncation),
-                       scratch, acc_out);
+    hipLaunchKernelGGL(loss_set_sizes_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, a);
     return eslam_check_launch("loss_set_sizes_kernel");
+}
+
+int eslam_shard_mark_args(const char* who, const eslam_plane_t* planes, const float* bound6_host, const float* rays_o,
+                          const float* rays_d, const float* gt_depth, int R, double truncation, const int64_t* block_base_host,
+                          int64_t n_blocks, uint8_t* touched, MarkArgs* m);
+
+extern "C" int eslam_shard_prologue(float* clear_flat, const int32_t* clear_idx, const int32_t* clear_meta, int64_t clear_capacity,
+                                    float* clear_tail, int64_t clear_n_tail, const float* rays_o, const float* rays_d,
+                                    const float* gt_depth, const uint8_t* ray_mask, int R, int n_strat, int n_imp,
+                                    double truncation, const float* t_free, const float* t_surf, int perturb, uint64_t seed,
+                                    const uint32_t* rng_state, uint32_t* sizes_scratch, float* acc_out,
+                                    const eslam_plane_t* mark_planes, const float* bound6_host, const int64_t* block_base_host,
+                                    int64_t n_blocks, uint8_t* touched, eslam_stream_t stream) {
+    SetSizesArgs sa;
+    if (int rc = fill_set_sizes_args("eslam_shard_prologue", gt_depth, ray_mask, R, n_strat, n_imp, truncation, t_free, t_surf,
+                                     nullptr, perturb, seed, rng_state, sizes_scratch, acc_out, &sa))
+        return rc;
+    ClearArgs ca = {};
+    int n_clear = 0;
+    if (clear_flat) {
+        if (!clear_idx || !clear_meta || clear_capacity <= 0 || clear_n_tail < 0 || (clear_n_tail > 0 && !clear_tail) ||
+            ((uintptr_t)clear_flat & 15) || clear_n_tail >= ((int64_t)1 << 30)) {
+            eslam_set_error("eslam_shard_prologue: bad clear arguments");
+            return 1;
+        }
+        ca.flat = clear_flat; ca.idx = clear_idx; ca.meta = clear_meta; ca.tail = clear_tail; ca.n_tail = (int)clear_n_tail;
+        const int64_t want = (clear_capacity + 31) / 32;
+        n_clear = (int)(want < 512 ? want : 512);
+    }
+    MarkArgs ma = {};
+    int n_mark = 0;
+    if (mark_planes) {
+        if (int rc = eslam_shard_mark_args("eslam_shard_prologue", mark_planes, bound6_host, rays_o, rays_d, gt_depth, R, truncation,
+                                           block_base_host, n_blocks, touched, &ma))
+            return rc;
+        n_mark = (R + 3) / 4 < 2048 ? (R + 3) / 4 : 2048;
+    }
+    const int n_sizes = (R + 3) / 4 < 1024 ? (R + 3) / 4 : 1024;
+    hipLaunchKernelGGL(shard_prologue_kernel, dim3(n_clear + n_sizes + n_mark), dim3(256), 0, (hipStream_t)stream, ca, n_clear, sa,
+                       n_sizes, ma, n_mark);
+    return eslam_check_launch("shard_prologue_kernel");
 }

@@ -718,90 +718,6 @@ __global__ __launch_bounds__(256) void scatter_fixed_to_float_kernel(float* __re
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Which texels WILL receive gradient: a function of the sample positions only, so it is known after the forward pass.
-// The ray-sharded mapper marks them here (one byte per texel = per 128-byte block of a channels_last plane), and the
-// ranks agree on the union while the backward pass is still running (myslam_amd/parallel.py).  The position and cell
-// arithmetic is the scatter's own, expression for expression, so the marked set contains every texel it adds to
-// (tests/test_gpu_callers.py checks the containment on the gradients themselves).
-// ---------------------------------------------------------------------------------------------------------
-struct BlockBase { int64_t b[NPL]; };
-
-__global__ __launch_bounds__(256) void mark_touched_kernel(const PlaneSet planes, const Bound bnd,
-                                                           const float* __restrict__ rays_o,
-                                                           const float* __restrict__ rays_d,
-                                                           const float* __restrict__ z_vals, int R, int S,
-                                                           const BlockBase base, uint8_t* __restrict__ touched) {
-    const int64_t pt0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = pt0 < (int64_t)R * S;
-    const int64_t pt = live ? pt0 : (int64_t)R * S - 1;             // keep the wave converged for the shuffles below
-    const int unit = (int)(pt / S);
-    const float zz = z_vals[pt];
-    float x = rays_o[unit * 3 + 0] + rays_d[unit * 3 + 0] * zz;
-    float y = rays_o[unit * 3 + 1] + rays_d[unit * 3 + 1] * zz;
-    float z = rays_o[unit * 3 + 2] + rays_d[unit * 3 + 2] * zz;
-    x = norm_coord(x, bnd.lo[0], bnd.hi[0]);
-    y = norm_coord(y, bnd.lo[1], bnd.hi[1]);
-    z = norm_coord(z, bnd.lo[2], bnd.hi[2]);
-#pragma unroll
-    for (int pi = 0; pi < NPL; ++pi) {
-        const int o = (pi % 6) >> 1;
-        const int pw = planes.p[pi].w, ph = planes.p[pi].h;
-        const AxisCoord ax = axis_coord((o == 2) ? y : x, pw);
-        const AxisCoord ay = axis_coord((o == 0) ? y : z, ph);
-        // neighbouring lanes are neighbouring samples of one ray and often sit in the same cell: only the first stores
-        const int cell = ay.i0 * pw + ax.i0;
-        const int prev = __shfl_up(cell, 1, WAVE);
-        if (live && (cell != prev || (threadIdx.x & 63) == 0)) {
-            uint8_t* t = touched + base.b[pi];
-            t[(int64_t)ay.i0 * pw + ax.i0] = 1;
-            t[(int64_t)ay.i0 * pw + ax.i1] = 1;
-            t[(int64_t)ay.i1 * pw + ax.i0] = 1;
-            t[(int64_t)ay.i1 * pw + ax.i1] = 1;
-        }
-    }
-}
-
-extern "C" int eslam_mark_touched(const eslam_plane_t* planes, const float* bound6_host, const float* rays_o,
-                                  const float* rays_d, const float* z_vals, int R, int S, const int64_t* block_base_host,
-                                  int64_t n_blocks, uint8_t* touched, eslam_stream_t stream) {
-    if (!planes || !bound6_host || !block_base_host || !touched || n_blocks <= 0) {
-        eslam_set_error("eslam_mark_touched: null argument");
-        return 1;
-    }
-    hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(touched, 0, (size_t)n_blocks, st) != hipSuccess) {
-        eslam_set_error("eslam_mark_touched: memset failed");
-        return 2;
-    }
-    if (R <= 0 || S <= 0) return 0;
-    if (!rays_o || !rays_d || !z_vals) {
-        eslam_set_error("eslam_mark_touched: null ray argument");
-        return 1;
-    }
-    PlaneSet ps;
-    BlockBase bb;
-    for (int i = 0; i < NPL; ++i) {
-        ps.p[i] = planes[i];
-        bb.b[i] = block_base_host[i];
-        // one block per texel needs the texel's 32 channels contiguous: channels_last planes only
-        if (planes[i].stride_c != 1 || planes[i].stride_x != ESLAM_C_DIM || planes[i].stride_y != (int64_t)ESLAM_C_DIM * planes[i].w) {
-            eslam_set_error("eslam_mark_touched: plane %d is not channels_last (use eslam_blocks_touched on the gradients)", i);
-            return 1;
-        }
-        if (bb.b[i] < 0 || bb.b[i] + (int64_t)planes[i].h * planes[i].w > n_blocks) {
-            eslam_set_error("eslam_mark_touched: block range of plane %d exceeds n_blocks", i);
-            return 1;
-        }
-    }
-    Bound bnd;
-    for (int k = 0; k < 3; ++k) { bnd.lo[k] = bound6_host[2 * k]; bnd.hi[k] = bound6_host[2 * k + 1]; }
-    const int64_t n = (int64_t)R * S;
-    hipLaunchKernelGGL(mark_touched_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ps, bnd, rays_o, rays_d,
-                       z_vals, R, S, bb, touched);
-    return eslam_check_launch("mark_touched_kernel");
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // host side (called from eslam_render_bwd.hip)
 // ---------------------------------------------------------------------------------------------------------
 static int env_int(const char* name, int dflt) {

@@ -69,10 +69,15 @@ class Workload:
             inside = ops.aabb_exit(ro, rd, ops.bound_to_host(sc.bound)) >= gd           # Mapper.py:322-332
         ro, rd, gd, gc = ro[inside], rd[inside], gd[inside], gc[inside]
         self.R_total = int(ro.shape[0])
+        # the WHOLE batch stays on every rank of a ray-sharded job (parallel.ShardedMapper forms the loss's global set sizes
+        # and the union of texels the batch can touch from it, instead of exchanging them)
+        self.all_rays_o, self.all_rays_d, self.all_gt_depth = ro.contiguous(), rd.contiguous(), gd.contiguous()
+        self.ray_lo = 0
         if shard is not None:
             from .parallel import shard_slice
             lo, hi = shard_slice(self.R_total, shard[0], shard[1])
             ro, rd, gd, gc = ro[lo:hi], rd[lo:hi], gd[lo:hi], gc[lo:hi]
+            self.ray_lo = lo
         self.rays_o = ro.contiguous().requires_grad_(rays_grad)
         self.rays_d = rd.contiguous().requires_grad_(rays_grad)
         self.gt_depth = gd.contiguous()

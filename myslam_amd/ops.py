@@ -276,9 +276,10 @@ class fused_loss:
     A ray-sharded caller all-reduces `.acc` in place before the backward; the backward then also rewrites `.value` with
     the global loss.  Mapping-style loss only (the tracker's outlier mask depends on the rendered depth itself)."""
 
-    def __init__(self, gt_depth, gt_color, truncation, weights5, ray_mask=None, rewrite_value=False):
+    def __init__(self, gt_depth, gt_color, truncation, weights5, ray_mask=None, rewrite_value=False, acc_out=None):
         self.gt_depth, self.gt_color, self.truncation, self.weights5, self.ray_mask = gt_depth, gt_color, truncation, weights5, ray_mask
         self.acc = self.value = self.loss = None
+        self.acc_out = acc_out          # optional float32 [16] the forward kernel writes the sums and set sizes into
         # what the backward needs, in an object of its own: the autograd node keeps THIS alive, not the context, which
         # holds .loss and would otherwise close a reference cycle around the saved activations (134 MB at 4096 x 64)
         self.state = _LossState(truncation, weights5, rewrite_value)
@@ -343,6 +344,120 @@ _rng_pending = {}
 
 def _rng_state(dev):
     return _cached(("rng_state", dev.index), lambda: torch.zeros(4, dtype=torch.int32, device=dev))
+
+
+# Reproducibility contract of the in-kernel random numbers (the jitter of Renderer.py:59 and the importance draw of
+# common.py:59 when nobody injects them): U = hash(key, step, stream, GLOBAL ray index, element).
+#   key   ops.seed(s) if called, else torch's seeds: the CPU generator's (torch.manual_seed) folded with the device
+#         generator's (torch.cuda.manual_seed) - re-seeding either gives a new key;
+#   step  a device counter the forward kernel advances; it restarts at 0 whenever the key changes, so seeding twice with
+#         the same value reproduces the same samples (a captured graph bakes the key in: re-seed before capturing);
+#   ray   ops.ray_offset(lo) + local index: the ranks of a ray-sharded iteration draw what the unsharded batch draws.
+_explicit_seed = None
+_rng_key = {}
+_ray_offset = 0
+
+
+def seed(value):
+    """Key the in-kernel random numbers explicitly (None: back to torch's seeds).  The step counter restarts."""
+    global _explicit_seed
+    _explicit_seed = None if value is None else int(value) & 0xFFFFFFFFFFFFFFFF
+    _rng_key.clear()
+
+
+def _rng_seed(dev):
+    if _explicit_seed is not None:
+        key = _explicit_seed
+    else:
+        gen = torch.cuda.default_generators[dev.index]
+        key = (torch.initial_seed() * 0x9E3779B97F4A7C15 + gen.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+    if _rng_key.get(dev.index) != key:
+        if not torch.cuda.is_current_stream_capturing():      # (a fill captured into a graph would restart the counter per replay)
+            _rng_key[dev.index] = key
+            _rng_state(dev).zero_()
+            _rng_pending.pop(dev.index, None)
+    return key
+
+
+_rng_override = None
+
+
+class rng_step:
+    """Context manager: sampler calls issued inside read the random-number step from `state` (int32 [4], element 0) instead of
+    the device's own counter, and the forward kernel does NOT advance it: the caller does (parallel.ShardedMapper advances it
+    with the last launch of its iteration - its set-size replay reads the same step on another stream)."""
+
+    def __init__(self, state):
+        self.state = state
+
+    def __enter__(self):
+        global _rng_override
+        self._prev, _rng_override = _rng_override, self.state
+
+    def __exit__(self, *a):
+        global _rng_override
+        _rng_override = self._prev
+
+
+class ray_offset:
+    """Context manager: the rays of render / sampler calls issued inside are rays lo, lo + 1, ... of the iteration's whole
+    batch (a ray-sharded rank rendering its slice): the in-kernel random numbers are keyed on the global index."""
+
+    def __init__(self, lo):
+        self.lo = int(lo)
+
+    def __enter__(self):
+        global _ray_offset
+        self._prev, _ray_offset = _ray_offset, self.lo
+
+    def __exit__(self, *a):
+        global _ray_offset
+        _ray_offset = self._prev
+
+
+def rng_step_snapshot(dev, out=None):
+    """A copy of the device step counter the NEXT sampler call will draw with (int32 [4]): lets loss_set_sizes run on another
+    stream beside the forward kernel, which advances the live counter."""
+    state = _rng_state(dev)
+    if _rng_pending.get(dev.index, False):
+        state[0] += 1                  # samples drawn earlier were never rendered: what the next sampler call would do
+        _rng_pending[dev.index] = False
+    _rng_seed(dev)                     # (a new seed restarts the counter: settle that before the copy)
+    if out is None:
+        return state.clone()
+    out.copy_(state)
+    return out
+
+
+def loss_set_sizes(gt_depth, ray_mask, n_strat, n_imp, truncation, perturb, t_rand=None, out=None, state=None):
+    """acc [16] with the mapping loss's five set sizes over ALL rays given (eslam_loss_set_sizes): what a ray-sharded rank
+    computes for the iteration's whole batch instead of all-reducing its shard's counts.  t_rand [R,S]: injected jitter
+    numbers (tests); None = the in-kernel numbers the sampler will draw for the same seed / step / global ray index - call
+    it BEFORE the forward kernel that consumes the samples (that kernel advances the step), or hand it a rng_step_snapshot
+    taken before as `state`."""
+    _hip.require_gpu_f32("gt_depth", gt_depth)
+    dev = gt_depth.device
+    gd = _c(gt_depth.detach().reshape(-1))
+    R = gd.shape[0]
+    if ray_mask is not None:
+        ray_mask = _c(ray_mask.view(torch.uint8) if ray_mask.dtype == torch.bool else ray_mask.to(torch.uint8))
+    # ticket + five counters, zeroed once and left zeroed by the kernel: a slot per (device, stream) out of the pre-zeroed pool
+    # the fused loss's scratch comes from (a buffer created inside a graph capture would be re-zeroed by a captured fill)
+    scratch = _pooled_scratch(dev, 7 * 32, "set_sizes")
+    acc = torch.empty(16, device=dev) if out is None else out
+    seed_v = 0 if t_rand is not None else _rng_seed(dev)
+    if state is None:
+        state = _rng_state(dev)
+        if t_rand is None and _rng_pending.get(dev.index, False):
+            state[0] += 1              # samples drawn earlier were never rendered: the sampler below will advance the step, too
+            _rng_pending[dev.index] = False
+    with _hip.on_device(dev):
+        _hip.check(_hip.lib().eslam_loss_set_sizes(_hip.ptr(gd), _hip.ptr(ray_mask), R, n_strat, n_imp, float(truncation),
+                                                  _hip.ptr(linspace01(n_strat, dev)), _hip.ptr(linspace01(n_imp, dev)),
+                                                  _hip.ptr(None if t_rand is None else _c(t_rand)), 1 if perturb else 0, seed_v,
+                                                  _hip.ptr(state), _hip.ptr(scratch), _hip.ptr(acc), _hip.stream_handle(dev)),
+                   "eslam_loss_set_sizes")
+    return acc
 
 
 def _take_rng_bump(dev):
@@ -413,7 +528,8 @@ class RenderFn(torch.autograd.Function):
                 mask = fl.ray_mask
                 if mask is not None:
                     mask = _c(mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8))
-                fl.acc, fl.value = torch.empty(16, device=dev), torch.empty((), device=dev)
+                fl.acc = torch.empty(16, device=dev) if getattr(fl, "acc_out", None) is None else fl.acc_out
+                fl.value = torch.empty((), device=dev)
                 st = fl.state
                 st.gt_depth, st.gt_color, st.ray_mask, st.acc, st.value = _c(fl.gt_depth), _c(fl.gt_color), mask, fl.acc, fl.value
                 w5 = (ctypes.c_float * 5)(*st.weights5)
@@ -736,8 +852,9 @@ def sample_z(rays_o, rays_d, gt_depth, all_planes, decoders, bound6, truncation,
         # the uniform numbers are drawn inside the sampler kernel, keyed on torch's seed and a device step counter
         z = torch.empty(R, S, device=dev)
         t_free, t_surf = linspace01(n_strat, dev), linspace01(n_imp, dev)
-        state = _rng_state(dev)
-        if _rng_pending.get(dev.index, False):
+        seed_v = _rng_seed(dev)
+        state = _rng_state(dev) if _rng_override is None else _rng_override
+        if _rng_override is None and _rng_pending.get(dev.index, False):
             state[0] += 1              # the previous samples were never rendered: advance the step here
         ro, rd = _c(rays_o.detach()), _c(rays_d.detach())
         arr, _ = _hip.make_planes(tuple([p.detach() for p in grp] for grp in all_planes))
@@ -746,10 +863,9 @@ def sample_z(rays_o, rays_d, gt_depth, all_planes, decoders, bound6, truncation,
         with _hip.on_device(dev):
             _hip.check(lib.eslam_sample_z_all_rng(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(ro), _hip.ptr(rd),
                                                   _hip.ptr(gd), R, n_strat, n_imp, float(truncation), _hip.ptr(t_free),
-                                                  _hip.ptr(t_surf), 1 if perturb else 0,
-                                                  torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, _hip.ptr(state), _hip.ptr(z),
-                                                  _hip.stream_handle(dev)), "eslam_sample_z_all_rng")
-        _rng_pending[dev.index] = True
+                                                  _hip.ptr(t_surf), 1 if perturb else 0, seed_v, _hip.ptr(state),
+                                                  _ray_offset, _hip.ptr(z), _hip.stream_handle(dev)), "eslam_sample_z_all_rng")
+        _rng_pending[dev.index] = _rng_override is None
         return z
     if rand is None:
         # one draw, three row-major blocks (the reference draws them in three calls, Renderer.py:59, common.py:59)
@@ -822,8 +938,18 @@ def _loss_scratch(dev, n_rays=0):
     on different streams need their own slot - capture them under ops.fresh_loss_scratch().)
     ESLAM_DEBUG_SCRATCH=1 checks on the host that the ticket counter is 0 before every use (a graph aborted between the
     adds and the last ticket leaves it non-zero): one sync per loss, for debugging only."""
-    need = int(_hip.lib().eslam_loss_scratch_floats(int(n_rays)))
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, _scratch_epoch)
+    t = _pooled_scratch(dev, int(_hip.lib().eslam_loss_scratch_floats(int(n_rays))), "loss")
+    if _DEBUG_SCRATCH and not torch.cuda.is_current_stream_capturing():
+        if int(t[:1].view(torch.int32).item()) != 0:
+            reset_loss_scratch(dev)
+            raise RuntimeError("loss scratch: the ticket counter was not 0 on entry - a previous loss evaluation on this stream "
+                               "did not finish (aborted graph?) or two streams shared a scratch; it has been reset")
+    return t
+
+
+def _pooled_scratch(dev, need, tag):
+    """`need` floats of scratch that were zero when handed out for the first time, one slot per (device, stream, tag)."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, _scratch_epoch, tag)
     t = _scratch_slots.get(key)
     if t is None or t.numel() < need:
         pool = _scratch_pool.get(dev.index)
@@ -832,11 +958,6 @@ def _loss_scratch(dev, n_rays=0):
         t = pool[0][pool[1]:pool[1] + need]
         pool[1] += (need + 31) // 32 * 32
         _scratch_slots[key] = t
-    if _DEBUG_SCRATCH and not torch.cuda.is_current_stream_capturing():
-        if int(t[:1].view(torch.int32).item()) != 0:
-            reset_loss_scratch(dev)
-            raise RuntimeError("loss scratch: the ticket counter was not 0 on entry - a previous loss evaluation on this stream "
-                               "did not finish (aborted graph?) or two streams shared a scratch; it has been reset")
     return t
 
 
@@ -860,8 +981,8 @@ class fresh_loss_scratch:
 
 def reset_loss_scratch(device=None):
     """eslam_loss_scratch_reset on every scratch slot (of one device): back to the freshly zeroed state."""
-    for (di, _, _), t in _scratch_slots.items():
-        if device is None or torch.device(device).index == di:
+    for (di, _, _, tag), t in _scratch_slots.items():
+        if tag == "loss" and (device is None or torch.device(device).index == di):
             with _hip.on_device(t.device):
                 _hip.check(_hip.lib().eslam_loss_scratch_reset(_hip.ptr(t), t.numel(), _hip.stream_handle(t.device)),
                            "eslam_loss_scratch_reset")

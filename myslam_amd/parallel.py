@@ -1,22 +1,28 @@
 """Ray-sharded data parallelism for mapping iterations - new, the reference is single-GPU.
 
-One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Planes and decoders are replicated; the
-rays of an iteration are split across ranks; rays are independent in the forward pass, so the only exchange steps are
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Planes and decoders are replicated; every
+rank draws the iteration's WHOLE batch of rays (same seed: the one torch.randint of get_samples, src/Mapper.py:318-319)
+and renders a contiguous slice of it.  Rays are independent in the forward pass; what the backward pass needs from the
+other ranks' rays is computed redundantly instead of exchanged (round 3; round 2 ran an int32 all-reduce between forward
+and backward and learnt the exchange's size through nonzero() on the host):
 
-  1. one int32 all-reduce(sum) between forward and backward (sync_pack / sync_unpack): the five sizes of the loss's masked
-     sets, so that every rank scales its upstream gradients by the GLOBAL denominators of the reference's means
-     (src/Mapper.py:136-140,343,346) and the summed gradients equal those of the unsharded batch - and, in the same
-     buffer, the union of the texels the ranks' backward passes will touch;
-  2. one all-reduce(sum) of the gradients: ONE flat float32 buffer holding the 12 plane gradients, the 2692 decoder
-     gradients, beta's and the loss's 16 sums (27.15 MB for room0, 70.5 MB for scene0000), of which only the union's
-     texels are exchanged (block-sparse) when the planes are channels_last.
+  * the five sizes of the loss's masked sets (the reference's means run over them, src/Mapper.py:136-140,343,346) depend
+    on gt_depth and on the depth-guided z_vals of the rays WITH depth only: eslam_loss_set_sizes replays that sampler for
+    the whole batch (the in-kernel random numbers are keyed on the GLOBAL ray index), ~10 us;
+  * the texels the batch CAN touch follow from ray geometry alone (eslam_mark_rays: a conservative rasterisation of every
+    ray's sample interval into the 12 planes), identical on every rank, known before anything is rendered;
 
-Identical optimiser steps on every rank then keep the replicas in sync without a broadcast.
-The flat buffer is also what RenderFn.backward scatters into (ops.grad_sink), so no copy sits between the backward
-kernels and the collective.  Tracking (pose-only, needs a global median) is not sharded: "replicas only".
+so ONE collective per iteration is left: an all-reduce(sum) of [dense tail | the marked texels' gradients] out of the ONE
+flat float32 buffer the backward kernels scatter into (12 plane gradients, 2692 decoder gradients, beta's, the window's
+pose gradients when joint_opt, the loss's 16 sums: 27.15 MB for room0, 70.5 MB for scene0000, of which 2-8 MB travel).
+The list of marked texels and its length stay on the device (eslam_blocks_compact); the host reads the length from pinned
+memory - written early in the iteration, while the GPU is still rendering - only to size the all-reduce.  Identical
+optimiser steps on every rank then keep the replicas in sync without a broadcast.  Tracking (pose-only, needs a global
+median) is not sharded: "replicas only".
 """
 import ctypes
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -31,54 +37,95 @@ def shard_slice(n, rank, world):
     return lo, min(n, lo + per)
 
 
-SYNC_HEAD = 8                                   # eslam_hip.h: words 0..4 = N_front, N_center, N_tail, N_depth, N_color
-_ACC_COUNT_SLOTS = (0, 1, 2, 6, 9)              # their slots in acc [16] (eslam_loss_final.h)
+_ACC_COUNT_SLOTS = (0, 1, 2, 6, 9)              # N_front, N_center, N_tail, N_depth, N_color in acc [16] (eslam_loss_final.h)
 _ACC_SUM_SLOTS = (3, 4, 5, 7, 8)                # S_front, S_center, S_tail, S_depth, S_color
-
-
-def sync_words(n_blocks):
-    return SYNC_HEAD + (n_blocks + 5) // 6
-
-
-def sync_pack(acc, touched, out):
-    """acc [16] float32 + touched [n] uint8 (or None) -> out [sync_words(n)] int32 (eslam_shard_sync_pack; the same
-    arithmetic in tensor ops on the CPU, which is what the gloo tests run)."""
-    n = 0 if touched is None else touched.numel()
-    if acc.is_cuda:
-        with _hip.on_device(acc.device):
-            _hip.check(_hip.lib().eslam_shard_sync_pack(_hip.ptr(acc), _hip.ptr(touched), n, _hip.ptr(out),
-                                                        _hip.stream_handle(acc.device)), "eslam_shard_sync_pack")
-        return out
-    out[:SYNC_HEAD] = 0
-    out[:5] = acc[list(_ACC_COUNT_SLOTS)].to(torch.int32)
-    if n:
-        pad = torch.zeros(6 * ((n + 5) // 6), dtype=torch.int32)
-        pad[:n] = (touched != 0).to(torch.int32)
-        out[SYNC_HEAD:] = (pad.view(-1, 6) << (4 * torch.arange(6, dtype=torch.int32))).sum(1).to(torch.int32)
-    return out
-
-
-def sync_unpack(buf, acc_local, acc_global, touched):
-    """Inverse of sync_pack after the SUM all-reduce: global set sizes into acc_global (the other slots copied from
-    acc_local), union of the touched texels into touched (eslam_shard_sync_unpack)."""
-    n = 0 if touched is None else touched.numel()
-    if buf.is_cuda:
-        with _hip.on_device(buf.device):
-            _hip.check(_hip.lib().eslam_shard_sync_unpack(_hip.ptr(buf), n, _hip.ptr(acc_local), _hip.ptr(acc_global),
-                                                          _hip.ptr(touched), _hip.stream_handle(buf.device)),
-                       "eslam_shard_sync_unpack")
-        return
-    acc_global.copy_(acc_local)
-    acc_global[list(_ACC_COUNT_SLOTS)] = buf[:5].to(acc_global.dtype)
-    if n:
-        nib = (buf[SYNC_HEAD:, None] >> (4 * torch.arange(6, dtype=torch.int32))) & 15
-        touched.copy_((nib.reshape(-1)[:n] != 0).to(torch.uint8))
 
 
 def loss_from_acc(acc, weights):
     """The loss value from the 16 accumulators (sums / set sizes), as eslam_loss_value forms it."""
     w = torch.tensor(weights, dtype=acc.dtype, device=acc.device)
     return (w * acc[list(_ACC_SUM_SLOTS)] / acc[list(_ACC_COUNT_SLOTS)]).sum()
+
+
+def set_sizes_from_z(z_vals, gt_depth, truncation, ray_mask=None):
+    """acc [16] with the five set sizes of the mapping loss (Mapper.py:124-140,343,346) from z_vals [R,S] of a whole batch:
+    the counting eslam_loss_set_sizes does on the GPU without materialising z_vals, in tensor ops (any device; the gloo tests
+    feed it the oracle's z_vals).  Only rows of rays with depth are looked at."""
+    m = gt_depth > 0
+    inb = torch.ones_like(m) if ray_mask is None else ray_mask.to(torch.bool)
+    m = m & inb
+    d = gt_depth[m][:, None]
+    z = z_vals[m]
+    front = z < d - truncation
+    back = z > d + truncation
+    center = (z > d - 0.4 * truncation) & (z < d + 0.4 * truncation)
+    tail = ~front & ~back & ~center
+    acc = torch.zeros(16, dtype=z_vals.dtype, device=z_vals.device)
+    for slot, v in zip(_ACC_COUNT_SLOTS, (front.sum(), center.sum(), tail.sum(), m.sum(), 3 * inb.sum())):
+        acc[slot] = v
+    return acc
+
+
+def mark_rays(plane_shapes, bound6, rays_o, rays_d, gt_depth, truncation, block_base, n_blocks, planes=None, out=None):
+    """touched uint8 [n_blocks]: 1 for every texel the rays CAN send gradient to (a conservative superset, from ray
+    geometry alone; eslam_mark_rays - see include/eslam_hip.h for the rule).  plane_shapes: 12 (h, w) in all_planes order;
+    block_base: index of each plane's first block.  On the GPU `planes` (the 6 groups of channels_last tensors) must be given;
+    on the CPU the same rule runs in tensor ops (what the gloo tests use)."""
+    R = int(rays_o.shape[0])
+    if rays_o.is_cuda:
+        touched = out if out is not None else torch.empty(n_blocks, dtype=torch.uint8, device=rays_o.device)
+        arr, _ = _hip.make_planes(tuple([p.detach() for p in grp] for grp in planes))
+        bb = (ctypes.c_int64 * 12)(*[int(b) for b in block_base])
+        with _hip.on_device(rays_o.device):
+            _hip.check(_hip.lib().eslam_mark_rays(arr, _hip.make_bound(bound6), _hip.ptr(ops._c(rays_o.detach())),
+                                                  _hip.ptr(ops._c(rays_d.detach())), _hip.ptr(ops._c(gt_depth)), R,
+                                                  float(truncation), bb, int(n_blocks), _hip.ptr(touched),
+                                                  _hip.stream_handle(rays_o.device)), "eslam_mark_rays")
+        return touched
+    touched = torch.zeros(n_blocks, dtype=torch.uint8) if out is None else out.zero_()
+    o, d, gd = rays_o.detach().double(), rays_d.detach().double(), gt_depth.double()
+    lo = torch.tensor(bound6[0::2], dtype=torch.float64)
+    hi = torch.tensor(bound6[1::2], dtype=torch.float64)
+    c15 = 1.5 * truncation
+    has = gd > 0
+    t_all = torch.stack([(lo - o) / d, (hi - o) / d], -1).max(-1).values.min(-1).values + 0.01
+    t0 = torch.where(has, torch.minimum(torch.zeros_like(gd), gd - c15), torch.zeros_like(gd))
+    t1 = torch.where(has, torch.maximum(1.2 * gd, gd + c15), t_all)
+    pad = 1e-5 * (t0.abs() + t1.abs()) + 1e-6
+    t0, t1 = t0 - pad, t1 + pad
+    eps = 0.02
+    for pi, (h, w) in enumerate(plane_shapes):
+        orient = (pi % 6) >> 1
+        au, av = (1 if orient == 2 else 0), (1 if orient == 0 else 2)
+        su, sv = (w - 1) / (hi[au] - lo[au]), (h - 1) / (hi[av] - lo[av])
+        ax, bx = (o[:, au] - lo[au]) * su, d[:, au] * su
+        ay, by = (o[:, av] - lo[av]) * sv, d[:, av] * sv
+        span = torch.maximum(bx.abs(), by.abs()) * (t1 - t0)
+        n = torch.where(torch.isfinite(span) & (span < 4096), span.ceil() + 1, torch.ones_like(span)).long()
+        nmax = int(n.max())
+        k = torch.arange(nmax, dtype=torch.float64)[None]                      # [1, nmax] steps, masked per ray
+        dt = ((t1 - t0) / n)[:, None]
+        ta = t0[:, None] + dt * k
+        tb = torch.where(k + 1 == n[:, None], t1[:, None].expand_as(ta), ta + dt)
+        live = k < n[:, None]
+
+        def rng(a, b, lim):
+            a0 = torch.nan_to_num(torch.minimum(a, b) - eps, nan=0.0).clamp(0, lim - 1).floor().long()
+            a1 = (torch.nan_to_num(torch.maximum(a, b) + eps, nan=0.0).clamp(0, lim - 1).floor().long() + 1).clamp(max=lim - 1)
+            return a0, a1
+        i0, i1 = rng(ax[:, None] + bx[:, None] * ta, ax[:, None] + bx[:, None] * tb, w)
+        j0, j1 = rng(ay[:, None] + by[:, None] * ta, ay[:, None] + by[:, None] * tb, h)
+        plane = touched[block_base[pi]:block_base[pi] + h * w].view(h, w)
+        # boxes are at most 4 x 4 for well-formed rays; degenerate ones (whole-plane boxes) are looped
+        wide = live & (((i1 - i0) > 3) | ((j1 - j0) > 3))
+        for r, s in wide.nonzero().tolist():
+            plane[j0[r, s]:j1[r, s] + 1, i0[r, s]:i1[r, s] + 1] = 1
+        live = live & ~wide
+        for dj in range(4):
+            for di in range(4):
+                ok = live & (j0 + dj <= j1) & (i0 + di <= i1)
+                plane[(j0 + dj)[ok], (i0 + di)[ok]] = 1
+    return touched
 
 
 class FlatGrads:
@@ -107,74 +154,24 @@ class FlatGrads:
             self.flat.zero_()
         self.clean = False
 
-    def zero_blocks_(self, idx, n_block_elems):
-        """Sparse clear: every non-zero of the first n_block_elems floats lies in the 32-float blocks `idx` (the union the
-        last exchange_blocks wrote back), the rest of the buffer (decoder gradients, loss sums) is dense and small."""
-        tail = self.flat[n_block_elems:]
-        if self.flat.is_cuda and self.flat.dtype == torch.float32:
-            with _hip.on_device(self.flat.device):
-                _hip.check(_hip.lib().eslam_blocks_zero(_hip.ptr(self.flat), _hip.ptr(idx), idx.numel(), _hip.ptr(tail),
-                                                        tail.numel(), _hip.stream_handle(self.flat.device)),
-                           "eslam_blocks_zero")
-        else:
-            self.flat[:n_block_elems].view(-1, 32).index_fill_(0, idx, 0.0)
-            tail.zero_()
-        self.clean = True
-
     def all_reduce(self, group=None, async_op=False):
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
-    def all_reduce_compact(self, n_block_elems, group=None, block=32):
-        """Sum over ranks, exchanging only the blocks of `block` floats that are non-zero on SOME rank.
-
-        The first n_block_elems floats (the planes: one block = one texel's 32 channels in channels_last planes) are
-        block-sparse after a mapping backward - a frame's rays touch 4-25 % of the texels, and
-        ranks that render the same keyframe window touch nearly the same ones - so the 27-70 MB dense all-reduce, which
-        is what bounds ray-sharded scaling over xGMI, becomes three steps:
-          1. all-reduce(MAX) of one byte per block (212 KB for room0)  -> the union of touched blocks, same on all ranks
-          2. gather the union's blocks + the dense tail (decoder / beta gradients) into one buffer, all-reduce(SUM)
-          3. scatter the blocks back.
-        `nonzero()` needs the union's size on the host: one stream synchronisation per step, which the collectives -
-        issued eagerly between the captured phases anyway - tolerate.  Plain tensor ops on purpose: the identical code
-        runs under gloo on the CPU in the tests, so the multi-rank logic is verified without multi-GPU hardware."""
+    def exchange_union(self, touched, n_block_elems, group=None, block=32):
+        """Sum over ranks, exchanging only the blocks of `block` floats marked in `touched` (identical on every rank: mark_rays)
+        plus the dense tail behind the first n_block_elems floats - in tensor ops, for any device and backend: what the gloo
+        tests run, and what ShardedMapper's device path (eslam_blocks_pack_dev -> all-reduce -> _unpack_dev) is checked
+        against.  Returns (bytes sent, bytes of a dense all-reduce)."""
         if n_block_elems % block:
-            raise RuntimeError("all_reduce_compact: the block-sparse prefix must be a multiple of the block size")
-        rows = self.flat[:n_block_elems].view(-1, block)
-        on_gpu = self.flat.is_cuda and self.flat.dtype == torch.float32 and block == 32
-        if on_gpu:                 # one launch for the bitmap
-            lib, dev = _hip.lib(), self.flat.device
-            touched = torch.empty(rows.shape[0], dtype=torch.uint8, device=dev)
-            with _hip.on_device(dev):
-                _hip.check(lib.eslam_blocks_touched(_hip.ptr(self.flat), rows.shape[0], _hip.ptr(touched),
-                                                    _hip.stream_handle(dev)), "eslam_blocks_touched")
-        else:
-            touched = (torch.count_nonzero(rows, dim=1) > 0).to(torch.uint8)
-        dist.all_reduce(touched, op=dist.ReduceOp.MAX, group=group)
-        idx = touched.nonzero().squeeze(1)                     # host sync: the union's size
-        return self.exchange_blocks(idx, n_block_elems, group, block)
-
-    def exchange_blocks(self, idx, n_block_elems, group=None, block=32):
-        """Steps 2 and 3 of all_reduce_compact for a union `idx` (ascending block indices, identical on every rank)."""
+            raise RuntimeError("exchange_union: the block-sparse prefix must be a multiple of the block size")
         rows = self.flat[:n_block_elems].view(-1, block)
         tail = self.flat[n_block_elems:]
-        k = idx.numel() * block
-        if self.flat.is_cuda and self.flat.dtype == torch.float32 and block == 32:
-            lib, dev = _hip.lib(), self.flat.device
-            buf = torch.empty(k + tail.numel(), device=dev)
-            with _hip.on_device(dev):
-                _hip.check(lib.eslam_blocks_pack(_hip.ptr(self.flat), _hip.ptr(idx), idx.numel(), _hip.ptr(tail),
-                                                 tail.numel(), _hip.ptr(buf), _hip.stream_handle(dev)), "eslam_blocks_pack")
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-            with _hip.on_device(dev):
-                _hip.check(lib.eslam_blocks_unpack(_hip.ptr(self.flat), _hip.ptr(idx), idx.numel(), _hip.ptr(tail),
-                                                   tail.numel(), _hip.ptr(buf), _hip.stream_handle(dev)),
-                           "eslam_blocks_unpack")
-        else:
-            buf = torch.cat([rows.index_select(0, idx).reshape(-1), tail])
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-            rows.index_copy_(0, idx, buf[:k].view(-1, block))
-            tail.copy_(buf[k:])
-        self.last_exchange = (int(buf.numel()) * buf.element_size() + rows.shape[0], self.flat.numel() * self.flat.element_size())
+        idx = touched.nonzero().squeeze(1)
+        buf = torch.cat([tail, rows.index_select(0, idx).reshape(-1)])
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        tail.copy_(buf[:tail.numel()])
+        rows.index_copy_(0, idx, buf[tail.numel():].view(-1, block))
+        self.last_exchange = (int(buf.numel()) * buf.element_size(), self.flat.numel() * self.flat.element_size())
         return self.last_exchange
 
     def assign(self):
@@ -183,150 +180,284 @@ class FlatGrads:
             p.grad = v
 
 
+class MappingWindow:
+    """The data of one mapped frame's optimisation (src/Mapper.py:235-306): the window's depth / colour images, its poses,
+    and - with joint_opt - the poses that are optimised (all but the first, Mapper.py:288-294).  `batch()` draws one
+    iteration's rays exactly as Mapper.py:308-332 does: get_samples over the whole window (ONE torch.randint - give every
+    rank the same seed and they draw the same pixels), differentiable in the optimised poses, then the AABB pre-filter as a
+    mask (static shapes, no host sync)."""
+
+    def __init__(self, renderer, gt_depths, gt_colors, c2ws, pixels, cam_poses=None):
+        from .src import common
+        self._common = common
+        self.renderer = renderer
+        self.gds, self.gcs, self.c2ws = gt_depths, gt_colors, c2ws
+        self.cam_poses = cam_poses                 # nn.Parameter [b-1,7] (quaternion real-first, translation) or None
+        self.n = int(pixels) // int(c2ws.shape[0])             # Mapper.py:249
+        self.R = self.n * int(c2ws.shape[0])
+
+    def batch(self, cam_poses=None):
+        """cam_poses: stand-in for self.cam_poses (ShardedMapper passes a fresh leaf per iteration and moves its gradient
+        into the flat buffer itself)."""
+        r = self.renderer
+        poses = self.cam_poses if cam_poses is None else cam_poses
+        c2ws = self.c2ws if poses is None else \
+            torch.cat([self.c2ws[0:1], self._common.cam_pose_to_matrix(poses)], 0)                     # Mapper.py:312-316
+        ro, rd, gd, gc = self._common.get_samples(0, r.H, 0, r.W, self.n, r.H, r.W, r.fx, r.fy, r.cx, r.cy, c2ws, self.gds,
+                                                  self.gcs, c2ws.device)
+        keep = ops.prefilter(ro, rd, gd, r._bound6, need_depth=False)                                  # Mapper.py:322-332
+        return ro, rd, gd, gc, keep
+
+
 class ShardedMapper:
-    """Drives one ray-sharded mapping iteration on this rank's shard (a harness.Workload holding this rank's rays).
+    """Drives ray-sharded mapping iterations on this rank.
 
-    step() = phase_a (sample, render forward with the loss's sums in its epilogue, texel marking, sync_pack)
-             -> ONE int32 all-reduce (global set sizes of the loss + union of touched texels) -> sync_unpack
-             -> phase_b (render backward, the loss's gradients formed inside the kernel from the global set sizes, into the
-                flat gradient buffer) -> exchange of that buffer (block-sparse over the union, or dense).
-    The phases contain no collective, so each can be captured into a hipGraph of its own (capture()); the two
-    collectives are issued eagerly between the replays - RCCL never has to run inside a captured graph.
+    step() = front (clear, the iteration's whole batch, texel marking + list, global set sizes, then THIS RANK'S SLICE:
+             sample, render forward with the loss's sums in its epilogue, backward with the loss's gradients formed inside
+             the kernel from the global set sizes, into the flat gradient buffer, pack)
+             -> ONE all-reduce of [tail | marked texels] -> back (unpack, optimiser).
+    front and back contain no collective and no host synchronisation: capture() records each as ONE hipGraph; the all-reduce
+    is issued eagerly between the replays, so RCCL never runs inside a captured graph.
 
-    optimizer: optional myslam_amd.optim.Adam over self.params (build it with make_optimizer): stepped after the
-    gradient exchange - every rank applies the same update to identical replicas, so they stay in sync without a
-    broadcast.  With fused_zero_grad it leaves the flat buffer zero, which saves the 27-70 MB
-    fill of the next iteration; under capture() it becomes a third graph (capturable=True is required for that)."""
+    source: a harness.Workload built with shard=(rank, world) - fixed rays, the bench's form - or a MappingWindow - fresh
+    pixels from a keyframe window every iteration, pose gradients in the flat buffer (the reference's iteration).
+    optimizer: optional myslam_amd.optim.Adam over self.params (build it with make_optimizer): stepped in `back` - every rank
+    applies the same update to identical replicas, so they stay in sync without a broadcast.  With fused_zero_grad it leaves
+    the flat buffer zero, which saves the next iteration's clear; under capture() it needs capturable=True.
+    compact=False (or ESLAM_DP_COMPACT=0, or planes that are not channels_last): dense all-reduce of the whole flat buffer."""
 
-    def __init__(self, workload, group=None, optimizer=None, compact=None):
+    def __init__(self, source, group=None, optimizer=None, compact=None, planes=None, decoders=None, truncation=None,
+                 weights=None):
         from . import losses
-        self.wl = workload
         self.group = group
-        self.weights = losses.MAPPING_W
-        world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        if world > 15:
-            raise RuntimeError("ShardedMapper: the sync buffer counts ranks per texel in 4 bits: at most 15 ranks")
-        self.params = workload.plane_list + ops.decoder_params(workload.decoders)
-        beta = workload.decoders.beta
+        self.weights = tuple(losses.MAPPING_W if weights is None else weights)
+        self._collective = dist.is_available() and dist.is_initialized()     # (a lone process without a group: nothing to sum with)
+        self.world = dist.get_world_size(group) if self._collective else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.window = source if isinstance(source, MappingWindow) else None
+        self.wl = None if self.window is not None else source
+        if self.window is not None:
+            self.renderer, self.planes, self.decoders, self.truncation = source.renderer, planes, decoders, float(truncation)
+            self.device = source.c2ws.device
+            self.R_total = source.R
+        else:
+            wl = source
+            self.renderer, self.planes, self.decoders, self.truncation = wl.renderer, wl.planes, wl.decoders, wl.truncation
+            self.device = wl.device
+            self.R_total = wl.R_total
+            lo, hi = shard_slice(wl.R_total, self.rank, self.world)
+            if wl.R != hi - lo or wl.ray_lo != lo:
+                raise RuntimeError("ShardedMapper: build the workload with shard=(rank, world) and the same seed on every rank: "
+                                   "each rank needs the iteration's whole batch")
+        self.lo, self.hi = shard_slice(self.R_total, self.rank, self.world)
+        self.plane_list = [p for grp in self.planes for p in grp]
+        self.params = self.plane_list + ops.decoder_params(self.decoders)
+        beta = self.decoders.beta
         self.has_beta = torch.is_tensor(beta)
         if self.has_beta:
             self.params = self.params + [beta]
+        self.pose_param = None if self.window is None else self.window.cam_poses
+        if self.pose_param is not None:
+            self.params = self.params + [self.pose_param]
         self.grads = FlatGrads(self.params, extra=16)          # + the loss's 16 sums: they ride in the gradient exchange
         self.optimizer = optimizer
-        # gradient exchange: block-sparse (FlatGrads.exchange_blocks) unless ESLAM_DP_COMPACT=0 / compact=False
-        self.compact = (os.environ.get("ESLAM_DP_COMPACT", "1") != "0") if compact is None else bool(compact)
-        self._n_plane_elems = sum(p.numel() for p in self.params[:12])
-        # With channels_last planes the union of touched texels is known from the sample positions right after the
-        # forward pass (eslam_mark_touched): the ranks agree on it - and the host learns its size - while the backward
-        # pass is still running, so the exchange itself follows the backward without a bubble.
-        planes = self.params[:12]
-        self._can_mark = bool(self.compact and planes[0].is_cuda and
-                              all(p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last) for p in planes))
-        dev = workload.device
-        n_blocks = self._n_plane_elems // 32 if self._can_mark else 0
-        self._touched = torch.zeros(n_blocks, dtype=torch.uint8, device=dev) if self._can_mark else None
-        self._sync = torch.zeros(sync_words(n_blocks), dtype=torch.int32, device=dev)
-        self._gacc = torch.zeros(16, device=dev)               # acc with the GLOBAL set sizes: what the backward scales by
-        if self._can_mark:
-            self._block_base = (ctypes.c_int64 * 12)(*[self.grads.offsets[i] // 32 for i in range(12)])
-            self._side = torch.cuda.Stream(device=dev)
+        self._n_plane_elems = sum(p.numel() for p in self.plane_list)
+        cl = all(p.is_cuda and p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last) for p in self.plane_list)
+        want = (os.environ.get("ESLAM_DP_COMPACT", "1") != "0") if compact is None else bool(compact)
+        self.compact = bool(want and cl)
+        dev = self.device
+        self._gacc = torch.zeros(16, device=dev)
+        self._bound6 = ops.bound_to_host(self.decoders.bound)          # what the forward / backward kernels normalise with
+        if self.compact:
+            self._n_blocks = self._n_plane_elems // 32
+            self._block_base = [self.grads.offsets[i] // 32 for i in range(12)]
+            self._touched = torch.zeros(self._n_blocks, dtype=torch.uint8, device=dev)
+            self._idx = torch.zeros(self._n_blocks, dtype=torch.int32, device=dev)
+            self._block_base_c = (ctypes.c_int64 * 12)(*self._block_base)
+            self._meta = torch.zeros(2, dtype=torch.int32, device=dev)            # [0] length of the list, [1] stamp
+            # the same two words in pinned host memory the compaction kernel writes itself (no copy node in the graph)
+            hp_, dp_ = ctypes.c_void_p(), ctypes.c_void_p()
+            with _hip.on_device(dev):
+                _hip.check(_hip.lib().eslam_host_meta_alloc(ctypes.byref(hp_), ctypes.byref(dp_)), "eslam_host_meta_alloc")
+            self._host_meta_ptr, self._host_meta_dev = hp_, dp_
+            self._meta_np = (ctypes.c_int32 * 2).from_address(hp_.value)
+            self._cscratch = torch.zeros(int(_hip.lib().eslam_blocks_compact_scratch_words(self._n_blocks)), dtype=torch.int32,
+                                         device=dev)
+            self._n_tail = self.grads.flat.numel() - self._n_plane_elems
+            self._tail_pad = (self._n_tail + 31) // 32 * 32
+            self._buf = torch.zeros(self._tail_pad + self._n_plane_elems, device=dev)   # fixed capacity: every block could be marked
+            self._stamp = 0                          # launches of the compaction so far (= meta[1] once they have run)
+        self._side = torch.cuda.Stream(device=dev)
+        self._step = torch.zeros(4, dtype=torch.int32, device=dev)       # random-number step of this mapper's iterations
         self._pre = None
         self._graphs = None
-        self._last_idx = None                      # union of the previous iteration's exchange: what a sparse clear must zero
+        self._pipeline = False
+        self._pending_back = False
+        self.last_exchange = None
 
+    def __del__(self):
+        hp_ = getattr(self, "_host_meta_ptr", None)
+        if hp_ is not None and hp_.value:
+            try:
+                torch.cuda.synchronize(self.device)          # (a replaying graph may still write there)
+                _hip.lib().eslam_host_meta_free(hp_)
+            except Exception:
+                pass
+            self._host_meta_ptr = None
+
+    # ------------------------------------------------------------------------------------------------------------
     @property
     def loss(self):
         """The global loss of the last step (from the 16 sums that came back with the gradient exchange)."""
         return loss_from_acc(self.grads.extra[:16], self.weights)
 
-    def phase_a(self):
+    def _batch(self, poses):
+        if self.window is not None:
+            return self.window.batch(poses)
         wl = self.wl
+        return wl.all_rays_o, wl.all_rays_d, wl.all_gt_depth, None, None
+
+    def front(self):
+        """Everything of an iteration in front of the all-reduce; no collective, no host synchronisation."""
+        dev, r = self.device, self.renderer
         for p in self.params:
             p.grad = None
-        with ops.keep_layout():                    # the backward scatters into the flat buffer's views: the planes' own strides
-            depth, color, sdf, z, pre = wl.renderer.render_batch_ray_with_loss(
-                wl.planes, wl.decoders, wl.rays_d, wl.rays_o, wl.device, wl.truncation, wl.gt_depth, wl.gt_color, self.weights)
-        pre.acc_global = self._gacc                # RenderFn.backward scales by these, not by this rank's own set sizes
+        # the window's poses enter the iteration as a FRESH leaf: its AccumulateGrad node is created on the stream this
+        # iteration runs (or is captured) on - the parameter's own node would stay bound to the stream of its first use
+        poses = None if self.pose_param is None else self.pose_param.detach().requires_grad_(True)
+        ro_all, rd_all, gd_all, gc_all, keep_all = self._batch(poses)
+        # Beside the sampler and the forward kernel, on a side stream, ONE launch (eslam_shard_prologue; a replayed graph pays
+        # ~3 us per node): the clear of the previous iteration's gradients, the loss's set sizes over the WHOLE batch (on a
+        # step counter of the mapper's own, advanced by the iteration's last launch) and the texels the whole batch can touch;
+        # then the texels' ascending list + length, which the kernel also writes to pinned memory for the host - it only needs
+        # the length to size the all-reduce.
+        step = self._step                            # the iteration's random-number step: read by the prologue (side stream) and the
+        ops._rng_seed(dev)                           # sampler (main stream), advanced by the pack kernel / an increment at the end
+        forked = torch.cuda.Event()
+        forked.record(torch.cuda.current_stream(dev))      # the side stream's work depends on nothing behind this point
+        lo, hi = self.lo, self.hi
+        if self.window is not None:
+            ro, rd, gd, gc = ro_all[lo:hi], rd_all[lo:hi], gd_all[lo:hi], gc_all[lo:hi]
+            keep = keep_all[lo:hi]
+        else:
+            wl = self.wl
+            ro, rd, gd, gc, keep = wl.rays_o, wl.rays_d, wl.gt_depth, wl.gt_color, None
+        with ops.keep_layout(), ops.ray_offset(lo), ops.rng_step(step):   # (keep_layout: the backward scatters into the flat buffer's views)
+            # (the forward kernel writes this rank's sums and set sizes straight into the flat buffer: summed with the gradients)
+            depth, color, sdf, z, pre = r.render_batch_ray_with_loss(self.planes, self.decoders, rd, ro, dev, self.truncation,
+                                                                     gd, gc, self.weights, ray_mask=keep,
+                                                                     acc_out=self.grads.extra[:16])
+        side = self._side
+        side.wait_event(forked)                      # ... enqueued BEHIND the sampler and the forward kernel: a replayed graph launches its
+        # nodes in this order, ~3 us apiece, and the side branch in front held the sampler back by 12 us
+        with torch.cuda.stream(side):
+            lib = _hip.lib()
+            clear = not self.grads.clean
+            tail = self.grads.flat[self._n_plane_elems:]
+            if clear and not self.compact:
+                self.grads.flat[:self.grads.offsets[-1]].zero_()
+            mask8 = None if keep_all is None else ops._c(keep_all.view(torch.uint8) if keep_all.dtype == torch.bool else keep_all.to(torch.uint8))
+            gd_c, ro_c, rd_c = ops._c(gd_all.detach()), ops._c(ro_all.detach()), ops._c(rd_all.detach())
+            arr = None
+            if self.compact:
+                arr, _ = _hip.make_planes(tuple([p.detach() for p in grp] for grp in self.planes))
+            with _hip.on_device(dev):
+                # (the clear leaves the 16 loss sums behind the gradients alone: the forward kernel, on the main stream, overwrites them)
+                _hip.check(lib.eslam_shard_prologue(
+                    _hip.ptr(self.grads.flat) if (clear and self.compact) else None, _hip.ptr(self._idx) if self.compact else None,
+                    _hip.ptr(self._meta) if self.compact else None, self._n_blocks if self.compact else 0, _hip.ptr(tail),
+                    tail.numel() - 16, _hip.ptr(ro_c), _hip.ptr(rd_c), _hip.ptr(gd_c), _hip.ptr(mask8), int(gd_c.shape[0]),
+                    r.n_stratified, r.n_importance, float(self.truncation), _hip.ptr(ops.linspace01(r.n_stratified, dev)),
+                    _hip.ptr(ops.linspace01(r.n_importance, dev)), 1 if r.perturb else 0, ops._rng_seed(dev), _hip.ptr(step),
+                    _hip.ptr(ops._pooled_scratch(dev, 7 * 32, "set_sizes")), _hip.ptr(self._gacc), arr,
+                    _hip.make_bound(self._bound6), self._block_base_c if self.compact else None, self._n_blocks if self.compact else 0,
+                    _hip.ptr(self._touched) if self.compact else None, _hip.stream_handle(dev)), "eslam_shard_prologue")
+            self.grads.clean = True
+            ready = torch.cuda.Event()
+            ready.record(side)                       # clear + set sizes: what the backward waits for
+            if self.compact:
+                with _hip.on_device(dev):
+                    _hip.check(lib.eslam_blocks_compact(_hip.ptr(self._touched), self._n_blocks, _hip.ptr(self._cscratch),
+                                                        _hip.ptr(self._idx), _hip.ptr(self._meta), self._host_meta_dev, 1,
+                                                        _hip.stream_handle(dev)), "eslam_blocks_compact")
+        pre.acc_global = self._gacc                  # RenderFn.backward scales by these, not by this rank's own set sizes
         self._pre = pre
-        ops.join_ray_order(wl.device)              # forward and backward are separate graphs: join the fork in this one
-        if self._can_mark:
-            arr, _ = _hip.make_planes(tuple([p.detach() for p in grp] for grp in wl.planes))
-            with _hip.on_device(wl.device):
-                # the marking must use the bound the forward and backward kernels normalise with (decoders.bound)
-                _hip.check(_hip.lib().eslam_mark_touched(arr, _hip.make_bound(ops.bound_to_host(wl.decoders.bound)),
-                                                         _hip.ptr(wl.rays_o.detach()), _hip.ptr(wl.rays_d.detach()),
-                                                         _hip.ptr(z), wl.R, wl.S, self._block_base,
-                                                         self._touched.numel(), _hip.ptr(self._touched),
-                                                         _hip.stream_handle(wl.device)), "eslam_mark_touched")
-        sync_pack(pre.acc, self._touched, self._sync)
-
-    def phase_b(self):
+        torch.cuda.current_stream(dev).wait_event(ready)
         with ops.grad_sink(self.grads):
-            self._pre.loss.backward()
-        self.grads.extra[:16].copy_(self._pre.acc)         # this rank's sums and set sizes: summed with the gradients
+            pre.loss.backward()
+        self.grads.clean = False
+        if poses is not None:                        # this rank's share of the pose gradients (its slice's rays), [b-1, 7]
+            self.grads.views[-1].copy_(poses.grad if poses.grad is not None else torch.zeros_like(poses))
+        _hip.stream_wait(dev, None, side)
+        if self.compact:
+            with _hip.on_device(dev):
+                _hip.check(_hip.lib().eslam_blocks_pack_dev(_hip.ptr(self.grads.flat), _hip.ptr(self._idx), _hip.ptr(self._meta),
+                                                            self._n_blocks, _hip.ptr(self.grads.flat[self._n_plane_elems:]),
+                                                            self._n_tail, self._tail_pad, _hip.ptr(self._buf), _hip.ptr(step),
+                                                            _hip.stream_handle(dev)), "eslam_blocks_pack_dev")
+        else:
+            step[0] += 1
 
-    def make_optimizer(self, lrs=(0.001, 0.005, 0.005), **kw):
-        """Adam with the mapper's three groups (decoders / planes / c_planes, src/Mapper.py:296-303;
-        learning rates of configs/ESLAM.yaml:58-61 by default).  Gradients are bound to the flat buffer's views."""
-        from . import optim
-        n_dec = len(self.params) - 12
+    def back(self):
+        """Behind the all-reduce: the summed gradients back into the flat buffer, then the optimiser."""
+        dev = self.device
+        if self.compact:
+            with _hip.on_device(dev):
+                _hip.check(_hip.lib().eslam_blocks_unpack_dev(_hip.ptr(self.grads.flat), _hip.ptr(self._idx), _hip.ptr(self._meta),
+                                                              self._n_blocks, _hip.ptr(self.grads.flat[self._n_plane_elems:]),
+                                                              self._n_tail, self._tail_pad, _hip.ptr(self._buf),
+                                                              _hip.stream_handle(dev)), "eslam_blocks_unpack_dev")
         self.grads.assign()
-        self.optimizer = optim.Adam([{"params": self.params[12:12 + n_dec], "lr": lrs[0]},
-                                     {"params": self.params[0:6], "lr": lrs[1]},
-                                     {"params": self.params[6:12], "lr": lrs[2]}], **kw)
+        if self.optimizer is not None:
+            self.optimizer.step()
+
+    def make_optimizer(self, lrs=(0.001, 0.005, 0.005), pose_lr=0.001, **kw):
+        """Adam with the mapper's groups (decoders / planes / c_planes [/ camera poses], src/Mapper.py:291-303; learning rates
+        of configs/ESLAM.yaml:58-61 by default).  Gradients are bound to the flat buffer's views."""
+        from . import optim
+        n_dec = 12 + (1 if self.has_beta else 0)
+        self.grads.assign()
+        groups = [{"params": self.params[12:12 + n_dec], "lr": lrs[0]}, {"params": self.params[0:6], "lr": lrs[1]},
+                  {"params": self.params[6:12], "lr": lrs[2]}]
+        if self.pose_param is not None:
+            groups.append({"params": [self.pose_param], "lr": pose_lr})
+        self.optimizer = optim.Adam(groups, **kw)
         return self.optimizer
 
-    def phase_c(self):
-        """Optimiser step on the all-reduced gradients (identical on every rank)."""
-        self.grads.assign()
-        self.optimizer.step()
-        if self.optimizer.fused_zero_grad:
-            self.grads.clean = True
+    def _marked(self):
+        """Length of this iteration's texel list, from pinned memory: the compaction ran early on the side stream, the main
+        stream is still rendering.  Waits (bounded) for the stamp of THIS iteration."""
+        self._stamp += 1
+        t0 = time.perf_counter()
+        while int(self._meta_np[1]) != self._stamp:
+            if time.perf_counter() - t0 > 20.0:
+                raise RuntimeError(f"ShardedMapper: the texel list of iteration {self._stamp} never arrived "
+                                   f"(pinned stamp {int(self._meta_np[1])})")
+        return int(self._meta_np[0])
+
+    def _run(self, run_front, run_back):
+        run_front()
+        if self.compact:
+            n = self._marked()
+            view = self._buf[:self._tail_pad + 32 * n]
+            if self._collective:
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            self.last_exchange = (view.numel() * 4, self.grads.flat.numel() * 4)
+        else:
+            if self._collective:
+                self.grads.all_reduce(self.group)
+            self.last_exchange = (self.grads.flat.numel() * 4,) * 2
+        run_back()
+        self.grads.clean = bool(self.optimizer is not None and self.optimizer.fused_zero_grad)
 
     def _eager(self):
-        return self._run(self.phase_a, self.phase_b, self.phase_c if self.optimizer is not None else None)
+        return self._run(self.front, self.back)
 
-    def _run(self, run_a, run_b, run_c):
-        """One iteration: phases a / b / c (eager calls or graph replays) with the collectives between them."""
-        if not self.grads.clean:
-            # the previous iteration's gradients are still in the flat buffer.  Its non-zero texels are the union that
-            # iteration exchanged: zero those (1.6-4.5 MB) instead of filling 27-70 MB.  (An optimiser with
-            # fused_zero_grad has left the buffer clean already.)
-            if self._last_idx is not None:
-                self.grads.zero_blocks_(self._last_idx, self._n_plane_elems)
-            else:
-                self.grads.flat.zero_()
-                self.grads.clean = True
-        run_a()
-        dist.all_reduce(self._sync, op=dist.ReduceOp.SUM, group=self.group)
-        sync_unpack(self._sync, self._pre.acc, self._gacc, self._touched)
-        ev = None
-        if self._can_mark:
-            ev = torch.cuda.Event()
-            ev.record()
-        run_b()                                    # enqueued before the host waits for the union below
-        if self._can_mark:
-            cur = torch.cuda.current_stream(self.wl.device)
-            with torch.cuda.stream(self._side):
-                self._side.wait_event(ev)
-                idx = self._touched.nonzero().squeeze(1)        # synchronises the SIDE stream only
-            cur.wait_stream(self._side)
-            idx.record_stream(cur)
-            self.grads.exchange_blocks(idx, self._n_plane_elems, self.group)
-            self._last_idx = idx
-        elif self.compact:
-            self.grads.all_reduce_compact(self._n_plane_elems, self.group)
-        else:
-            self.grads.all_reduce(self.group)
-        self.grads.clean = False                   # (a replayed phase_b cannot flip the flag itself)
-        self.grads.assign()
-        if run_c is not None:
-            run_c()
-            if self.optimizer.fused_zero_grad:
-                self.grads.clean = True            # the Adam pass zeroed what it consumed (also when it was a graph replay)
-
-    def capture(self, warmup=3):
-        """Capture phase_a and phase_b into two hipGraphs sharing one memory pool; step() then replays them."""
+    def capture(self, warmup=3, pipeline=False):
+        """Capture front and back into two hipGraphs sharing one memory pool; step() then replays them.
+        pipeline=True: ONE graph per step - [back of the previous iteration, front of this one] - and the all-reduce behind it
+        (a graph launch costs ~10 us of its own): after step() the newest gradients sit all-reduced in the exchange buffer and
+        are unpacked (and applied by the optimiser) at the head of the next step, or by flush()."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -334,25 +465,47 @@ class ShardedMapper:
                 self._eager()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga, capture_error_mode="thread_local"):
-            self.phase_a()
-        self.grads.clean = True                    # step() clears the buffer before every replay: no fill inside the graph
-        with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
-            self.phase_b()
-        self.grads.clean = False                   # (the capture ran nothing: the warm-up's gradients are still there)
-        gc = None
-        if self.optimizer is not None:
-            if not self.optimizer.capturable:
-                raise RuntimeError("capture() needs an optimiser built with capturable=True")
-            gc = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gc, pool=ga.pool(), capture_error_mode="thread_local"):
-                self.phase_c()
+        if self.optimizer is not None and not self.optimizer.capturable:
+            raise RuntimeError("capture() needs an optimiser built with capturable=True")
+        clean_in_graph = bool(self.optimizer is not None and self.optimizer.fused_zero_grad)
+        if not clean_in_graph and self.grads.clean:
+            raise RuntimeError("capture(): run one eager step first (the captured clear works from the previous step's texel list)")
+        gf, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self.grads.clean = clean_in_graph            # without a zeroing optimiser the sparse clear is part of the graph
+        with torch.cuda.graph(gf, capture_error_mode="thread_local"):
+            if pipeline:
+                self.back()
+                self.grads.clean = clean_in_graph
+            self.front()
+        with torch.cuda.graph(gb, pool=gf.pool(), capture_error_mode="thread_local"):
+            self.back()
         torch.cuda.synchronize()
-        self._graphs = (ga, gb, gc)
+        self.grads.clean = clean_in_graph            # (the capture ran nothing: the buffer is as the last eager step left it)
+        self._graphs = (gf, gb)
+        self._pipeline = bool(pipeline)
+        self._pending_back = False                   # pipeline: the last step's gradients are still waiting in the exchange buffer
+        if pipeline:
+            # prime the pipeline: one eager iteration up to and including its all-reduce; the first replay opens with its `back`
+            if not clean_in_graph:
+                self.grads.clean = False
+            self._run(self.front, lambda: None)
+            self._pending_back = True
+
+    def flush(self):
+        """pipeline mode: unpack (and apply) the gradients of the last step() now."""
+        if getattr(self, "_pipeline", False) and self._pending_back:
+            self._graphs[1].replay()
+            self._pending_back = False
+            self.grads.clean = bool(self.optimizer is not None and self.optimizer.fused_zero_grad)
 
     def step(self):
         if self._graphs is None:
             return self._eager()
-        ga, gb, gc = self._graphs
-        return self._run(ga.replay, gb.replay, gc.replay if gc is not None else None)
+        gf, gb = self._graphs
+        if not self._pipeline:
+            return self._run(gf.replay, gb.replay)
+        if not self._pending_back:                   # after a flush(): re-prime with an eager front, as capture() did
+            self._run(self.front, lambda: None)
+        else:
+            self._run(gf.replay, lambda: None)
+        self._pending_back = True

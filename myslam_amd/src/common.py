@@ -85,7 +85,7 @@ def cam_pose_to_matrix(batch_poses):
     reference converts keyframe poses on the CPU, too) through the same formula in tensor ops."""
     if batch_poses.is_cuda and batch_poses.dtype == torch.float32 and batch_poses.dim() == 2 and batch_poses.shape[1] == 7:
         return ops.PoseToMatrixFn.apply(batch_poses)
-    c2w = torch.eye(4, device=batch_poses.device).unsqueeze(0).repeat(batch_poses.shape[0], 1, 1)
+    c2w = torch.eye(4, device=batch_poses.device, dtype=batch_poses.dtype).unsqueeze(0).repeat(batch_poses.shape[0], 1, 1)
     c2w[:, :3, :3] = quaternion_to_matrix(batch_poses[:, :4])
     c2w[:, :3, 3] = batch_poses[:, 4:]
     return c2w

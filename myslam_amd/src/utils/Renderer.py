@@ -54,11 +54,11 @@ class Renderer(object):
         return outs[0], outs[1], outs[2], z_vals
 
     def render_batch_ray_with_loss(self, all_planes, decoders, rays_d, rays_o, device, truncation, gt_depth, gt_color,
-                                   weights, ray_mask=None, _rand=None):
+                                   weights, ray_mask=None, _rand=None, acc_out=None):
         """render_batch_ray + the mapping loss (src/Mapper.py:337-346): its sums are formed in the forward kernel's
         epilogue and its gradients inside the backward kernel.  Returns (depth, rgb, sdf, z_vals, pre); pre.loss is the
         loss (losses.mapping_loss(..., precomputed=pre) returns it): call .backward() on it."""
-        with ops.fused_loss(gt_depth, gt_color, truncation, weights, ray_mask) as pre:
+        with ops.fused_loss(gt_depth, gt_color, truncation, weights, ray_mask, acc_out=acc_out) as pre:
             depth, rgb, sdf, z_vals = self.render_batch_ray(all_planes, decoders, rays_d, rays_o, device, truncation,
                                                             gt_depth=gt_depth, _rand=_rand)
         return depth, rgb, sdf, z_vals, pre

@@ -166,32 +166,53 @@ def _free_port():
     return p
 
 
-def _dp_worker(rank, world, port, ret, compact):
-    """One gloo rank: oracle forward on its ray shard, two-phase loss with all-reduced denominators, gradients
-    all-reduced through parallel.FlatGrads - the same sequence parallel.ShardedMapper runs on the GPU."""
-    import torch.distributed as dist
+def _window_problem(dtype=torch.float64):
+    """A small mapping iteration on the CPU with the oracle standing in for the kernels: a window of three cameras (the first
+    pose fixed, the other two optimised: src/Mapper.py:288-294,312-316), pixels drawn once for the whole window
+    (Mapper.py:318-319), the AABB pre-filter as a mask (Mapper.py:322-332), 15 % of the pixels without depth."""
     from oracle import eslam_oracle as orc
-    from myslam_amd.parallel import FlatGrads, shard_slice
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.set_num_threads(2)
+    from myslam_amd import scene as scn, synth
+    from myslam_amd.src import common
+    sc = scn.make_scene("room0")
+    planes = scn.synth_planes(sc, dtype=dtype, channels_last=True)
+    planes = tuple([p.requires_grad_(True) for p in grp] for grp in planes)
     fx = hp.load("room0_200x40_zero15")
-    sc, planes = hp.scene_and_planes(fx, dtype=torch.float64, channels_last=True, requires_grad=True)
-    params = hp.params_from(fx, dtype=torch.float64, requires_grad=True)
-    beta = torch.tensor([10.0], dtype=torch.float64, requires_grad=True)
-    t_rand, t_uni, u = (t.double() for t in hp.rand_inputs(fx))
-    lo, hi = shard_slice(int(fx["R_eff"]), rank, world)
-    sl = slice(lo, hi)
-    ro = torch.from_numpy(fx["rays_o"]).double()[sl]
-    rd = torch.from_numpy(fx["rays_d"]).double()[sl]
-    gd = torch.from_numpy(fx["gt_depth"]).double()[sl]
-    gc = torch.from_numpy(fx["gt_color"]).double()[sl]
-    tr = float(fx["truncation"])
-    depth, color, sdf, z = orc.render_batch_ray(planes, params, beta, sc.bound, rd, ro, tr, gd, 32, 8, t_rand[sl],
-                                                t_uni[sl], u[sl])
-    # phase 1: local set sizes and squared-error sums (what eslam_loss_reduce accumulates) -> all-reduce
-    m = gd > 0
+    params = hp.params_from(fx, dtype=dtype, requires_grad=True)
+    beta = torch.tensor([10.0], dtype=dtype, requires_grad=True)
+    b, n, ns, ni = 3, 40, 24, 8
+    c0 = scn.center_pose(sc).to(dtype)
+    c2ws = c0[None].repeat(b, 1, 1)
+    for k in range(1, b):
+        q = torch.tensor([1.0, 0.03 * k, -0.02 * k, 0.05 * k], dtype=dtype)
+        c2ws[k, :3, :3] = common.quaternion_to_matrix(q / q.norm()) @ c0[:3, :3]
+        c2ws[k, :3, 3] += torch.tensor([0.3 * k, -0.2 * k, 0.1], dtype=dtype)
+    poses = common.matrix_to_cam_pose(c2ws[1:]).detach().clone().requires_grad_(True)
+    depths = torch.stack([torch.from_numpy(synth.depth_image(sc.H, sc.W, 20 + k, 0.15)).to(dtype) for k in range(b)])
+    depths[1] *= 2.6                               # some depths beyond the bound: the pre-filter mask drops those rays
+    colors = torch.stack([torch.from_numpy(synth.color_image(sc.H, sc.W, 30 + k)).to(dtype) for k in range(b)])
+    idx = torch.from_numpy(synth.hash_randint(sc.H * sc.W, (b * n,), 777))
+    R, S = b * n, ns + ni
+    t_rand = torch.from_numpy(synth.hash_uniform((R, S), 91)).to(dtype)
+    t_uni = torch.from_numpy(synth.hash_uniform((R, ns), 92)).to(dtype)
+    u = torch.from_numpy(synth.hash_uniform((R, ni), 93)).to(dtype)
+
+    def rays():
+        c = torch.cat([c2ws[0:1], common.cam_pose_to_matrix(poses)], 0)
+        ro, rd, gd, gc = orc.rays_from_pixels(idx, 0, sc.H, 0, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, c, depths, colors)
+        with torch.no_grad():
+            keep = orc.aabb_exit(ro, rd, sc.bound.to(dtype)) >= gd
+        return ro, rd, gd, gc, keep
+
+    def render(sl, ro, rd, gd):
+        return orc.render_batch_ray(planes, params, beta, sc.bound, rd[sl], ro[sl], sc.truncation, gd[sl], ns, ni, t_rand[sl],
+                                    t_uni[sl], u[sl])
+    plist = hp.flat_planes(planes) + [params[k] for k in orc.DECODER_KEYS] + [beta, poses]
+    return dict(sc=sc, planes=planes, plist=plist, rays=rays, render=render, t_rand=t_rand, ns=ns, ni=ni, R=R, orc=orc)
+
+
+def _local_sums(depth, color, sdf, z, gd, gc, keep, tr):
+    """This rank's five squared-error sums of the mapping loss (what the forward kernel's epilogue accumulates)."""
+    m = (gd > 0) & keep
     d = gd[m][:, None]
     zz, ss = z[m], sdf[m]
     front = zz < d - tr
@@ -199,90 +220,119 @@ def _dp_worker(rank, world, port, ret, compact):
     center = (zz > d - 0.4 * tr) & (zz < d + 0.4 * tr)
     tail = ~front & ~back & ~center
     pred = zz + ss * tr
-    sums = torch.stack([((ss - 1) ** 2)[front].sum(), ((pred - d) ** 2)[center].sum(), ((pred - d) ** 2)[tail].sum(),
-                        ((gd[m] - depth[m]) ** 2).sum(), ((gc - color) ** 2).sum()])
-    cnts = torch.tensor([front.sum(), center.sum(), tail.sum(), m.sum(), gc.numel()], dtype=torch.float64)
-    dist.all_reduce(cnts)
-    # phase 2: local loss scaled by GLOBAL denominators; its gradient is this rank's share of the global gradient
-    w = orc.MAPPING_W
-    wv = torch.tensor([w["w_fs"], w["w_center"], w["w_tail"], w["w_depth"], w["w_color"]], dtype=torch.float64)
-    local = (wv * sums / cnts).sum()
-    plist = hp.flat_planes(planes) + [params[k] for k in orc.DECODER_KEYS] + [beta]
-    fg = FlatGrads(plist)
-    grads = torch.autograd.grad(local, plist)
-    for v, g in zip(fg.views, grads):
-        v.copy_(g)
-    if compact:      # block-sparse exchange: only the texel rows some rank touched, plus the dense decoder tail
-        sent, dense = fg.all_reduce_compact(sum(p.numel() for p in plist[:12]))
-        if rank == 0:
-            ret["exchange"] = (sent, dense)
-    else:
-        fg.all_reduce()
-    fg.assign()
-    total = local.detach().clone()
-    dist.all_reduce(total)
-    if rank == 0:
-        ret["loss"] = float(total)
-        ret["flat"] = fg.flat.clone().numpy()
-        ret["strides_ok"] = all(p.grad.stride() == p.stride() for p in plist)
-    dist.destroy_process_group()
+    return torch.stack([((ss - 1) ** 2)[front].sum(), ((pred - d) ** 2)[center].sum(), ((pred - d) ** 2)[tail].sum(),
+                        ((gd[m] - depth[m]) ** 2).sum(), ((gc[keep] - color[keep]) ** 2).sum()])
 
 
-@pytest.mark.parametrize("world,compact", [(2, False), (2, True), (3, True)])
-def test_ray_sharded_data_parallel_equals_single_process(world, compact):
-    import torch.multiprocessing as mp
-    from tests.test_oracle_golden import run_oracle
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    port = _free_port()
-    mp.spawn(_dp_worker, args=(world, port, ret, compact), nprocs=world, join=True)
-    fx = hp.load("room0_200x40_zero15")
-    ref = run_oracle(fx, torch.float64)
-    assert abs(ret["loss"] - float(ref["loss"])) <= 1e-10 * abs(float(ref["loss"]))
-    from oracle import eslam_oracle as orc
-    ref_list = [p.grad for p in hp.flat_planes(ref["planes"])] + [ref["params"][k].grad for k in orc.DECODER_KEYS] + \
-               [ref["beta"].grad]
-    # flat buffer holds the gradients in the parameters' own (channels-last) memory order
-    flat_ref = np.concatenate([g.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(-1).numpy()
-                               if g.dim() == 4 else g.reshape(-1).numpy() for g in ref_list])
-    assert ret["strides_ok"]
-    assert np.abs(ret["flat"] - flat_ref).max() <= 1e-9 * np.abs(flat_ref).max()
-    if compact:
-        sent, dense = ret["exchange"]
-        assert sent < 0.5 * dense, (sent, dense)          # 200 rays touch a small part of the 27 MB of planes
-
-
-def _sync_worker(rank, world, port, ret):
+def _dp_worker(rank, world, port, ret, compact):
+    """One gloo rank of the collective-free scheme parallel.ShardedMapper runs on the GPU: every rank draws the WHOLE batch,
+    forms the loss's global set sizes from the whole batch's depth-guided z_vals (no exchange) and the union of texels the
+    batch can touch from ray geometry (no exchange), renders ITS SLICE, and ONE all-reduce sums [tail | marked texels] of
+    the flat gradient buffer - pose gradients of the window included."""
     import torch.distributed as dist
     from myslam_amd import parallel
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    n = 1000
-    g = torch.Generator().manual_seed(100 + rank)
-    acc = torch.floor(torch.rand(16, generator=g) * 1000)
-    touched = (torch.rand(n, generator=g) < 0.1).to(torch.uint8)
-    buf = parallel.sync_pack(acc, touched, torch.zeros(parallel.sync_words(n), dtype=torch.int32))
-    dist.all_reduce(buf)
-    gacc, union = torch.zeros(16), torch.zeros(n, dtype=torch.uint8)
-    parallel.sync_unpack(buf, acc, gacc, union)
-    ret[rank] = (acc.numpy(), touched.numpy(), gacc.numpy(), union.numpy())
+    torch.set_num_threads(2)
+    pr = _window_problem()
+    sc, orc = pr["sc"], pr["orc"]
+    tr = sc.truncation
+    ro, rd, gd, gc, keep = pr["rays"]()
+    lo, hi = parallel.shard_slice(pr["R"], rank, world)
+    sl = slice(lo, hi)
+    # global set sizes, redundantly: the depth-guided sampler of the whole batch (rows of rays without depth are not looked at)
+    z_all = torch.zeros(pr["R"], pr["ns"] + pr["ni"], dtype=torch.float64)
+    has = gd > 0
+    z_all[has] = orc.depth_guided_z(gd[has], pr["ns"], pr["ni"], tr, pr["t_rand"][has])
+    acc = parallel.set_sizes_from_z(z_all, gd.detach(), tr, keep)
+    cnts = acc[list(parallel._ACC_COUNT_SLOTS)]
+    depth, color, sdf, z = pr["render"](sl, ro, rd, gd)
+    assert torch.equal(z[has[sl]], z_all[sl][has[sl]])          # the replayed sampler IS the render's sampler
+    sums = _local_sums(depth, color, sdf, z, gd[sl], gc[sl], keep[sl], tr)
+    w = orc.MAPPING_W
+    wv = torch.tensor([w["w_fs"], w["w_center"], w["w_tail"], w["w_depth"], w["w_color"]], dtype=torch.float64)
+    local = (wv * sums / cnts).sum()              # local sums over GLOBAL denominators: this rank's share of the loss
+    plist = pr["plist"]
+    fg = parallel.FlatGrads(plist, extra=16)
+    for v, g in zip(fg.views, torch.autograd.grad(local, plist)):
+        v.copy_(g)
+    fg.extra[list(parallel._ACC_SUM_SLOTS)] = sums.detach()
+    fg.extra[list(parallel._ACC_COUNT_SLOTS)] = torch.zeros(5, dtype=torch.float64)      # (the global counts are known everywhere)
+    n_plane = sum(p.numel() for p in plist[:12])
+    if compact:
+        shapes = [(p.shape[2], p.shape[3]) for p in plist[:12]]
+        base = [fg.offsets[i] // 32 for i in range(12)]
+        touched = parallel.mark_rays(shapes, [float(v) for v in sc.bound.reshape(-1)], ro.detach(), rd.detach(), gd.detach(), tr,
+                                     base, n_plane // 32)
+        nz = (fg.flat[:n_plane].view(-1, 32) != 0).any(1)
+        assert bool((touched.bool() | ~nz).all()), "a texel outside the conservative marking received gradient"
+        sent, dense = fg.exchange_union(touched, n_plane)
+        if rank == 0:
+            ret["exchange"] = (sent, dense, int(touched.sum()))
+            ret["touched"] = touched.numpy().copy()
+    else:
+        fg.all_reduce()
+    fg.assign()
+    if rank == 0:
+        ret["loss"] = float((wv * fg.extra[list(parallel._ACC_SUM_SLOTS)] / cnts).sum())
+        ret["flat"] = fg.flat[:fg.offsets[-1]].clone().numpy()
+        ret["strides_ok"] = all(p.grad.stride() == p.stride() for p in plist)
+        ret["pose_grad"] = plist[-1].grad.clone().numpy()
     dist.destroy_process_group()
 
 
-def test_sync_collective_gives_global_set_sizes_and_the_union():
-    """The ONE int32 all-reduce between forward and backward of the ray-sharded step (parallel.sync_pack / sync_unpack):
-    3 gloo ranks end with the summed set sizes and the union of their touched texels; the loss's sums stay local."""
+@pytest.mark.parametrize("world,compact", [(2, False), (2, True), (3, True)])
+def test_ray_sharded_mapping_iteration_equals_single_process(world, compact):
+    """2 / 3 gloo ranks, dense and marked-texel exchange: the summed flat buffer - plane, decoder, beta AND pose gradients of a
+    keyframe window with joint_opt - equals the unsharded iteration's gradients to float64 rounding; no collective besides
+    the one gradient all-reduce."""
     import torch.multiprocessing as mp
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_sync_worker, args=(3, _free_port(), ret), nprocs=3, join=True)
-    accs = np.stack([ret[r][0] for r in range(3)])
-    union = np.maximum.reduce([ret[r][1] for r in range(3)])
-    for r in range(3):
-        gacc, u = ret[r][2], ret[r][3]
-        assert np.array_equal(u, union)
-        for k in (0, 1, 2, 6, 9):
-            assert gacc[k] == accs[:, k].sum()
-        for k in (3, 4, 5, 7, 8):
-            assert gacc[k] == accs[r, k]
+    mp.spawn(_dp_worker, args=(world, _free_port(), ret, compact), nprocs=world, join=True)
+    pr = _window_problem()
+    sc, orc = pr["sc"], pr["orc"]
+    ro, rd, gd, gc, keep = pr["rays"]()
+    depth, color, sdf, z = pr["render"](slice(0, pr["R"]), ro, rd, gd)
+    loss = orc.mapping_loss(depth[keep], color[keep], sdf[keep], z[keep], gd[keep], gc[keep], sc.truncation)   # Mapper.py:329-346
+    assert 0.5 < float(keep.float().mean()) < 0.98 and 0 < int((gd[keep] == 0).sum())
+    grads = torch.autograd.grad(loss, pr["plist"])
+    assert abs(ret["loss"] - float(loss)) <= 1e-10 * abs(float(loss))
+    flat_ref = np.concatenate([g.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(-1).numpy()
+                               if g.dim() == 4 else g.reshape(-1).numpy() for g in grads])
+    assert ret["strides_ok"]
+    assert np.abs(ret["flat"] - flat_ref).max() <= 1e-9 * np.abs(flat_ref).max()
+    gp = grads[-1].numpy()
+    assert np.abs(gp).max() > 0 and np.abs(ret["pose_grad"] - gp).max() <= 1e-9 * np.abs(gp).max()
+    if compact:
+        sent, dense, marked = ret["exchange"]
+        assert sent < 0.5 * dense, (sent, dense)          # 120 rays can touch a small part of the 27 MB of planes
+        # the marking is conservative (every texel with gradient is marked) but not loose
+        n_plane = sum(p.numel() for p in pr["plist"][:12])
+        nz = (np.abs(flat_ref[:n_plane].reshape(-1, 32)) > 0).any(1)
+        assert not (nz & (ret["touched"] == 0)).any()
+        assert marked <= 4 * int(nz.sum()), (marked, int(nz.sum()))
+
+
+def test_set_sizes_from_z_counts_the_loss_regions():
+    """parallel.set_sizes_from_z against the oracle's own masks (src/Mapper.py:124-134), with a ray mask."""
+    from oracle import eslam_oracle as orc
+    from myslam_amd import parallel
+    g = torch.Generator().manual_seed(5)
+    gd = torch.rand(50, generator=g) * 2 + 0.3
+    gd[::7] = 0
+    keep = torch.rand(50, generator=g) > 0.2
+    tr = 0.06
+    z = torch.zeros(50, 40)
+    has = gd > 0
+    z[has] = orc.depth_guided_z(gd[has], 32, 8, tr, torch.rand(int(has.sum()), 40, generator=g))
+    acc = parallel.set_sizes_from_z(z, gd, tr, keep)
+    m = has & keep
+    d = gd[m][:, None]
+    front = z[m] < d - tr
+    back = z[m] > d + tr
+    center = (z[m] > d - 0.4 * tr) & (z[m] < d + 0.4 * tr)
+    want = [front.sum(), center.sum(), (~front & ~back & ~center).sum(), m.sum(), 3 * keep.sum()]
+    assert [int(acc[k]) for k in parallel._ACC_COUNT_SLOTS] == [int(v) for v in want]
+    assert float(acc[list(parallel._ACC_SUM_SLOTS)].abs().sum()) == 0.0

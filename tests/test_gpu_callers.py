@@ -137,75 +137,134 @@ def test_tracking_loss_masked_equals_compacted():
         assert hp.rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 1e-6
 
 
-def test_block_sparse_exchange_kernels():
-    """eslam_blocks_touched / pack / unpack against the tensor ops parallel.FlatGrads.all_reduce_compact uses on the CPU."""
-    import ctypes
+def test_texel_list_and_block_move_kernels():
+    """eslam_blocks_compact (ascending list + length of the marked texels, on the device) and eslam_blocks_pack_dev /
+    _unpack_dev / _zero_dev against the tensor ops parallel.FlatGrads.exchange_union runs under gloo."""
     from myslam_amd import _hip
     dev = _dev()
     lib = _hip.lib()
     g = torch.Generator().manual_seed(5)
-    n_blocks, n_tail = 10007, 2693
-    rows = torch.randn(n_blocks, 32, generator=g)
-    rows[torch.rand(n_blocks, generator=g) < 0.8] = 0.0            # 80 % empty blocks
-    rows[5, :] = 0.0
-    rows[5, 31] = -0.0                                             # a negative zero is still zero
-    rows[7, :] = 0.0
-    rows[7, 17] = 1e-30                                            # a single tiny value marks the block
-    flat = torch.cat([rows.reshape(-1), torch.randn(n_tail, generator=g)]).to(dev)
-    touched = torch.empty(n_blocks, dtype=torch.uint8, device=dev)
     st = _hip.stream_handle(dev)
-    _hip.check(lib.eslam_blocks_touched(_hip.ptr(flat), n_blocks, _hip.ptr(touched), st), "touched")
-    ref_t = (torch.count_nonzero(rows, dim=1) > 0)
-    assert torch.equal(touched.cpu().bool(), ref_t) and not bool(touched[5]) and bool(touched[7])
-    idx = touched.nonzero().squeeze(1)
-    tail = flat[n_blocks * 32:]
-    buf = torch.empty(idx.numel() * 32 + n_tail, device=dev)
-    _hip.check(lib.eslam_blocks_pack(_hip.ptr(flat), _hip.ptr(idx), idx.numel(), _hip.ptr(tail), n_tail, _hip.ptr(buf), st), "pack")
-    assert torch.equal(buf.cpu(), torch.cat([rows[ref_t].reshape(-1), flat[n_blocks * 32:].cpu()]))
-    before = flat.clone()
-    buf.mul_(3.0)
-    _hip.check(lib.eslam_blocks_unpack(_hip.ptr(flat), _hip.ptr(idx), idx.numel(), _hip.ptr(tail), n_tail, _hip.ptr(buf), st), "unpack")
-    assert torch.equal(flat, before * 3.0)                         # untouched blocks are zero either way
-    # empty union, empty tail
-    z = torch.zeros(64, device=dev)
-    t2 = torch.empty(2, dtype=torch.uint8, device=dev)
-    _hip.check(lib.eslam_blocks_touched(_hip.ptr(z), 2, _hip.ptr(t2), st), "touched")
-    assert t2.tolist() == [0, 0]
-    assert lib.eslam_blocks_pack(_hip.ptr(z), None, 0, None, 0, _hip.ptr(z), st) == 0
+    for n_blocks, dens in ((10007, 0.2), (4096, 1.0), (4097, 0.0), (16, 0.5), (212_345, 0.13)):
+        n_tail, tail_pad = 2693 + 147, 2848
+        touched = (torch.rand(n_blocks, generator=g) < dens).to(torch.uint8) * 3          # any non-zero byte marks
+        rows = torch.randn(n_blocks, 32, generator=g)
+        flat = torch.cat([rows.reshape(-1), torch.randn(n_tail, generator=g)]).to(dev)
+        td = touched.to(dev)
+        scratch = torch.zeros(int(lib.eslam_blocks_compact_scratch_words(n_blocks)), dtype=torch.int32, device=dev)
+        idx = torch.full((n_blocks,), -1, dtype=torch.int32, device=dev)
+        meta = torch.tensor([-5, 41], dtype=torch.int32, device=dev)
+        _hip.check(lib.eslam_blocks_compact(_hip.ptr(td), n_blocks, _hip.ptr(scratch), _hip.ptr(idx), _hip.ptr(meta), None, 0, st), "compact")
+        want = touched.nonzero().squeeze(1)
+        n = int(meta[0])
+        assert n == want.numel() and int(meta[1]) == 42                   # the stamp counts launches
+        assert torch.equal(idx[:n].cpu().long(), want) and torch.equal(td.cpu(), touched)
+        # again, with the list's length + stamp written to pinned host memory by the kernel and the map cleared behind the read
+        import ctypes
+        hp_, dp_ = ctypes.c_void_p(), ctypes.c_void_p()
+        _hip.check(lib.eslam_host_meta_alloc(ctypes.byref(hp_), ctypes.byref(dp_)), "host_meta_alloc")
+        host = (ctypes.c_int32 * 2).from_address(hp_.value)
+        idx2 = torch.full((n_blocks,), -1, dtype=torch.int32, device=dev)
+        _hip.check(lib.eslam_blocks_compact(_hip.ptr(td), n_blocks, _hip.ptr(scratch), _hip.ptr(idx2), _hip.ptr(meta), dp_, 1, st), "compact")
+        torch.cuda.synchronize()
+        assert (host[0], host[1]) == (n, 43) and int(meta[1]) == 43
+        assert torch.equal(idx2[:n], idx[:n]) and int(td.count_nonzero()) == 0
+        _hip.check(lib.eslam_host_meta_free(hp_), "host_meta_free")
+        tail = flat[n_blocks * 32:]
+        buf = torch.full((tail_pad + n_blocks * 32,), 7.0, device=dev)
+        step = torch.tensor([5, 0, 0, 0], dtype=torch.int32, device=dev)
+        _hip.check(lib.eslam_blocks_pack_dev(_hip.ptr(flat), _hip.ptr(idx), _hip.ptr(meta), n_blocks, _hip.ptr(tail), n_tail,
+                                             tail_pad, _hip.ptr(buf), _hip.ptr(step), st), "pack")
+        assert int(step[0]) == 6                                           # the iteration's random-number step, advanced here
+        ref = torch.cat([flat[n_blocks * 32:].cpu(), torch.zeros(tail_pad - n_tail), rows[want].reshape(-1)])
+        assert torch.equal(buf[:tail_pad + 32 * n].cpu(), ref)
+        assert n == n_blocks or float(buf[tail_pad + 32 * n]) == 7.0         # nothing written past the list
+        before = flat.clone()
+        buf[:tail_pad + 32 * n].mul_(3.0)
+        _hip.check(lib.eslam_blocks_unpack_dev(_hip.ptr(flat), _hip.ptr(idx), _hip.ptr(meta), n_blocks, _hip.ptr(tail), n_tail,
+                                               tail_pad, _hip.ptr(buf), st), "unpack")
+        exp = before.clone()
+        exp[:n_blocks * 32].view(-1, 32)[want.to(dev)] *= 3.0
+        exp[n_blocks * 32:] *= 3.0
+        assert torch.equal(flat, exp)                                      # unlisted blocks untouched
+        _hip.check(lib.eslam_blocks_zero_dev(_hip.ptr(flat), _hip.ptr(idx), _hip.ptr(meta), n_blocks, _hip.ptr(tail), n_tail, st), "zero")
+        exp[:n_blocks * 32].view(-1, 32)[want.to(dev)] = 0.0
+        exp[n_blocks * 32:] = 0.0
+        assert torch.equal(flat, exp)
 
 
-@pytest.mark.parametrize("scene,zero_frac", [("room0", 0.0), ("toy", 0.2)])
-def test_marked_texels_contain_every_block_the_backward_touches(scene, zero_frac):
-    """eslam_mark_touched (from sample positions, after the forward) must be a superset of the non-zero 128-byte blocks
-    of the plane gradients (eslam_blocks_touched after the backward) - the block-sparse exchange relies on it."""
-    import ctypes
-    from myslam_amd import harness, ops, _hip
-    from myslam_amd.parallel import FlatGrads
+@pytest.mark.parametrize("scene,zero_frac,state", [("room0", 0.0, "initial"), ("toy", 0.2, "initial"), ("scene0000", 0.1, "trained")])
+def test_rays_marking_contains_every_block_the_backward_touches(scene, zero_frac, state):
+    """eslam_mark_rays (from ray geometry alone, before anything is sampled) must be a superset of the non-zero 128-byte
+    blocks of the plane gradients after a backward with fresh random jitter - the ray-sharded exchange relies on it - and
+    equals the tensor-op form the gloo tests run on the CPU."""
+    from myslam_amd import harness, ops, parallel
     dev = _dev()
-    wl = harness.make_workload(scene, 3000, 40, 8, device=dev, zero_frac=zero_frac)
+    wl = harness.make_workload(scene, 3000, 40, 8, device=dev, zero_frac=zero_frac, state=state)
     params = wl.plane_list + ops.decoder_params(wl.decoders) + [wl.decoders.beta]
-    fg = FlatGrads(params)
-    depth, color, sdf, z = wl.renderer.render_batch_ray(wl.planes, wl.decoders, wl.rays_d, wl.rays_o, dev, wl.truncation,
-                                                        gt_depth=wl.gt_depth)
+    fg = parallel.FlatGrads(params)
     n_blocks = sum(p.numel() for p in wl.plane_list) // 32
-    marked = torch.empty(n_blocks, dtype=torch.uint8, device=dev)
-    base = (ctypes.c_int64 * 12)(*[fg.offsets[i] // 32 for i in range(12)])
-    arr, _ = _hip.make_planes(tuple([p.detach() for p in grp] for grp in wl.planes))
-    st = _hip.stream_handle(dev)
-    _hip.check(_hip.lib().eslam_mark_touched(arr, _hip.make_bound(ops.bound_to_host(wl.scene.bound)), _hip.ptr(wl.rays_o),
-                                             _hip.ptr(wl.rays_d), _hip.ptr(z), wl.R, wl.S, base, n_blocks,
-                                             _hip.ptr(marked), st), "eslam_mark_touched")
-    with ops.grad_sink(fg):
-        ((depth * wl._cot[0]).sum() + (color * wl._cot[1]).sum() + (sdf * wl._cot[2]).sum()).backward()
-    nz = torch.empty(n_blocks, dtype=torch.uint8, device=dev)
-    _hip.check(_hip.lib().eslam_blocks_touched(_hip.ptr(fg.flat), n_blocks, _hip.ptr(nz), st), "eslam_blocks_touched")
-    torch.cuda.synchronize()
-    assert int(nz.sum()) > 100
-    assert int((nz.bool() & ~marked.bool()).sum()) == 0, "a texel received gradient without being marked"
-    # ... and not wildly larger: samples behind the surface have transmittance exactly 0 in float32, so the colour planes'
-    # texels there are visited but receive exact zeros - the marked set is up to ~3x the non-zero set, still a small
-    # fraction of the 212 k blocks
-    assert int(marked.sum()) <= 4 * int(nz.sum()) and int(marked.sum()) < 0.3 * n_blocks
+    base = [fg.offsets[i] // 32 for i in range(12)]
+    b6 = ops.bound_to_host(wl.scene.bound)
+    marked = parallel.mark_rays(None, b6, wl.rays_o, wl.rays_d, wl.gt_depth, wl.truncation, base, n_blocks, planes=wl.planes)
+    for it in range(3):                                   # three draws of the jitter / importance samples
+        depth, color, sdf, z = wl.renderer.render_batch_ray(wl.planes, wl.decoders, wl.rays_d, wl.rays_o, dev, wl.truncation,
+                                                            gt_depth=wl.gt_depth)
+        fg.flat.zero_()
+        with ops.grad_sink(fg):
+            ((depth * wl._cot[0]).sum() + (color * wl._cot[1]).sum() + (sdf * wl._cot[2]).sum()).backward()
+        nz = (fg.flat[:n_blocks * 32].view(-1, 32) != 0).any(1)
+        assert int(nz.sum()) > 100
+        assert int((nz & ~marked.bool()).sum()) == 0, "a texel received gradient without being marked"
+    # conservative, not loose: a few times the touched set, a small part of the planes
+    assert int(marked.sum()) <= 5 * int(nz.sum()) and int(marked.sum()) < 0.4 * n_blocks, (int(marked.sum()), int(nz.sum()), n_blocks)
+    shapes = [(p.shape[2], p.shape[3]) for p in wl.plane_list]
+    cpu = parallel.mark_rays(shapes, b6, wl.rays_o.detach().cpu(), wl.rays_d.detach().cpu(), wl.gt_depth.cpu(), wl.truncation, base, n_blocks)
+    # float32 on the device, float64 in the tensor-op form: the boxes differ only where a coordinate sits within rounding of the
+    # MARK_EPS margin
+    diff = int((cpu.bool() != marked.cpu().bool()).sum())
+    assert diff <= 0.002 * int(marked.sum()) + 4, (diff, int(marked.sum()))
+
+
+def test_loss_set_sizes_equal_the_forward_kernels_counts():
+    """eslam_loss_set_sizes (the five set sizes of a whole batch without rendering it: the depth-guided sampler replayed in
+    LDS) against the counts the forward kernel's loss epilogue forms for the same rays - injected jitter numbers, in-kernel
+    numbers (same seed, step and GLOBAL ray index), a ray mask, 10 % depth-less rays; the slices' counts add up."""
+    from myslam_amd import harness, losses, ops, parallel
+    dev = _dev()
+    wl = harness.make_workload("scene0000", 2000, 88, 8, device=dev, zero_frac=0.1)
+    g = torch.Generator().manual_seed(9)
+    keep = (torch.rand(wl.R, generator=g) > 0.15).to(dev)
+    r = wl.renderer
+    cs = list(parallel._ACC_COUNT_SLOTS)
+    for mask in (None, keep):
+        # in-kernel numbers: set sizes first (the forward kernel advances the step), then the render of the whole batch
+        acc = ops.loss_set_sizes(wl.gt_depth, mask, r.n_stratified, r.n_importance, wl.truncation, True)
+        with torch.no_grad():
+            _, _, _, z, pre = r.render_batch_ray_with_loss(wl.planes, wl.decoders, wl.rays_d, wl.rays_o, dev, wl.truncation,
+                                                           wl.gt_depth, wl.gt_color, losses.MAPPING_W, ray_mask=mask)
+        assert torch.equal(acc[cs], pre.acc[cs]), (acc[cs], pre.acc[cs])
+        assert float(acc[cs].min()) > 0 and float(acc[list(parallel._ACC_SUM_SLOTS)].abs().sum()) == 0.0
+        assert torch.equal(acc[cs], parallel.set_sizes_from_z(z, wl.gt_depth, wl.truncation, mask)[cs])
+        # two slices rendered under ops.ray_offset draw the whole batch's numbers: their counts add up to the same sizes
+        acc2 = ops.loss_set_sizes(wl.gt_depth, mask, r.n_stratified, r.n_importance, wl.truncation, True)
+        parts = []
+        for lo, hi in ((0, 700), (700, wl.R)):
+            if lo > 0:
+                ops._rng_state(dev)[0] -= 1            # (same step as the first slice: a sharded rank renders ONE slice per step)
+            with torch.no_grad(), ops.ray_offset(lo):
+                _, _, _, _, p2 = r.render_batch_ray_with_loss(wl.planes, wl.decoders, wl.rays_d[lo:hi], wl.rays_o[lo:hi], dev,
+                                                              wl.truncation, wl.gt_depth[lo:hi], wl.gt_color[lo:hi], losses.MAPPING_W,
+                                                              ray_mask=None if mask is None else mask[lo:hi])
+            parts.append(p2.acc[cs].clone())
+        assert torch.equal(acc2[cs], parts[0] + parts[1])
+    # injected numbers
+    t_rand = wl._rand[0]
+    acc = ops.loss_set_sizes(wl.gt_depth, None, r.n_stratified, r.n_importance, wl.truncation, True, t_rand=t_rand)
+    with torch.no_grad():
+        _, _, _, z, pre = r.render_batch_ray_with_loss(wl.planes, wl.decoders, wl.rays_d, wl.rays_o, dev, wl.truncation, wl.gt_depth,
+                                                       wl.gt_color, losses.MAPPING_W, _rand=wl._rand)
+    assert torch.equal(acc[cs], pre.acc[cs])
 
 
 @pytest.mark.parametrize("cameras,R", [(1, 4096), (1, 77), (3, 3000), (1, 9000)])
@@ -233,31 +292,6 @@ def test_ray_order_is_a_permutation_and_groups_neighbours(cameras, R):
         step_sorted = (dn[p[1:n1]] - dn[p[:n1 - 1]]).norm(dim=1).mean()
         step_given = (dn[1:n1] - dn[:n1 - 1]).norm(dim=1).mean()
         assert float(step_sorted) < 0.1 * float(step_given)
-
-
-def test_shard_sync_pack_unpack_match_the_tensor_ops():
-    """eslam_shard_sync_pack / _unpack (the one collective between forward and backward of the ray-sharded step) against
-    the tensor-op form parallel.sync_pack / sync_unpack run on the CPU under gloo."""
-    from myslam_amd import parallel
-    dev = torch.device("cuda:0")
-    g = torch.Generator().manual_seed(3)
-    for n in (0, 1, 5, 6, 7, 1003, 212_345):
-        acc = torch.floor(torch.rand(16, generator=g) * 1e5)
-        acc[3] = 0.37
-        t = (torch.rand(n, generator=g) < 0.3).to(torch.uint8) * 7 if n else None
-        ref = parallel.sync_pack(acc, t, torch.zeros(parallel.sync_words(n), dtype=torch.int32))
-        got = parallel.sync_pack(acc.to(dev), None if t is None else t.to(dev),
-                                 torch.full((parallel.sync_words(n),), -1, dtype=torch.int32, device=dev))
-        assert torch.equal(got.cpu()[:5], ref[:5]) and torch.equal(got.cpu()[8:], ref[8:])
-        tot = ref * 3                                     # as if three ranks had contributed the same buffer
-        ga, gt = torch.zeros(16), (torch.zeros(n, dtype=torch.uint8) if n else None)
-        parallel.sync_unpack(tot, acc, ga, gt)
-        da, dt = torch.zeros(16, device=dev), (torch.full((n,), 9, dtype=torch.uint8, device=dev) if n else None)
-        parallel.sync_unpack(tot.to(dev), acc.to(dev), da, dt)
-        assert torch.equal(da.cpu(), ga)
-        assert float(ga[0]) == 3 * float(acc[0]) and float(ga[3]) == float(acc[3])
-        if n:
-            assert torch.equal(dt.cpu(), gt) and torch.equal(gt, (t != 0).to(torch.uint8))
 
 
 def test_in_kernel_jitter_is_uniform_fresh_per_step_and_reproducible():
@@ -307,6 +341,31 @@ def test_in_kernel_jitter_is_uniform_fresh_per_step_and_reproducible():
     assert abs(float((a * b).mean()) * 12) < 0.03
     a, b = tt[:-1, 2:20].reshape(-1) - 0.5, tt[1:, 2:20].reshape(-1) - 0.5
     assert abs(float((a * b).mean()) * 12) < 0.03
+    # the reproducibility contract (ops._rng_seed): the key folds torch's CPU seed with the device generator's, or is given by
+    # ops.seed; a new key restarts the step counter, so seeding twice with one value reproduces the samples
+    torch.manual_seed(77)
+    za = render()
+    assert int(ops._rng_state(dev)[0]) == 1 and not torch.equal(za, z1)
+    torch.manual_seed(1234)
+    assert torch.equal(render(), z1)
+    torch.cuda.manual_seed(5)                                     # the device generator alone
+    zc = render()
+    assert int(ops._rng_state(dev)[0]) == 1 and not torch.equal(zc, z1)
+    ops.seed(99)
+    zd = render()
+    ops.seed(99)
+    assert torch.equal(render(), zd) and not torch.equal(zd, z1)
+    ops.seed(None)
+    # rays lo .. of a batch rendered under ops.ray_offset(lo) draw the numbers of the whole batch's rows lo ..
+    ops.seed(4321)
+    zw = render()
+    ops.seed(4321)                                                # (restarts the step counter)
+    with torch.no_grad(), ops.ray_offset(500):
+        zs = r.render_batch_ray(wl.planes, wl.decoders, wl.rays_d[500:900], wl.rays_o[500:900], dev, wl.truncation,
+                                gt_depth=wl.gt_depth[500:900])[3]
+    assert torch.equal(zs[has[500:900]], zw[500:900][has[500:900]])          # depth-guided rows: bit for bit
+    assert torch.allclose(zs, zw[500:900], rtol=1e-5, atol=1e-6)
+    ops.seed(None)
 
 
 def test_integration_md_ctypes_snippet_runs_as_written():
