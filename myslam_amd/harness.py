@@ -94,10 +94,16 @@ class Workload:
 
     @property
     def plane_list(self):
-        return [p for grp in self.planes for p in grp]
+        pl = getattr(self, "_plane_list", None)
+        if pl is None or pl[0] is not self.planes[0][0]:
+            pl = self._plane_list = [p for grp in self.planes for p in grp]
+        return pl
 
     def params(self):
-        return self.plane_list + list(self.decoders.parameters())
+        ps = getattr(self, "_params", None)
+        if ps is None:          # (walking the module tree costs ~12 us a call, and a step asks twice)
+            ps = self._params = self.plane_list + list(self.decoders.parameters())
+        return ps
 
     def _slice(self, shard):
         if shard is None:

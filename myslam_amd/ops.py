@@ -5,6 +5,7 @@ Nothing in this file computes on the CPU: tensors that are not on a GPU raise.
 """
 import ctypes
 import os
+import sys
 
 import torch
 
@@ -53,10 +54,20 @@ def _decoder_params_slow(decoders):
             decoders.c_linears[1].bias, decoders.c_output_linear.weight, decoders.c_output_linear.bias]
 
 
+_bound_last = None
+
+
 def bound_to_host(bound):
-    """[3,2] tensor (the reference keeps decoders.bound on the CPU, ESLAM.py:173) -> 6 floats."""
+    """[3,2] tensor (the reference keeps decoders.bound on the CPU, ESLAM.py:173) -> 6 floats.  The last tensor's values are
+    remembered (same object, same version counter: a render call asks twice per iteration)."""
+    global _bound_last
     if torch.is_tensor(bound):
-        return tuple(float(v) for v in bound.detach().reshape(-1).tolist())
+        last = _bound_last
+        if last is not None and last[0] is bound and last[1] == bound._version:
+            return last[2]
+        vals = tuple(float(v) for v in bound.detach().reshape(-1).tolist())
+        _bound_last = (bound, bound._version, vals)
+        return vals
     return tuple(float(v) for v in bound)
 
 
@@ -90,6 +101,7 @@ class grad_sink:
 
 
 _grad_layout_cache = {}
+_grad_reuse = {}
 
 
 def _alloc_plane_grads(planes, zero=True):
@@ -106,8 +118,26 @@ def _alloc_plane_grads(planes, zero=True):
             off += p.numel()
         layout = _grad_layout_cache[key] = (layout, off)
     entries, total = layout
-    flat = (torch.zeros if zero else torch.empty)(total, device=planes[0].device, dtype=torch.float32)
-    return flat, [torch.as_strided(flat, shp, st, off) for shp, st, off in entries]
+    dev = planes[0].device
+    # The previous call's buffer and its 12 views are handed out again when NOBODY else holds them any more (the caller dropped
+    # the gradients: optimizer.zero_grad(set_to_none=True), p.grad = None): 13 tensor constructions (~30 us of host time per
+    # iteration) become 12 reference-count reads.  A view that is still somebody's .grad keeps its count up, and a fresh
+    # buffer is built.
+    ck = (key, dev.index)
+    old = _grad_reuse.get(ck)
+    if old is not None and not torch.cuda.is_current_stream_capturing():
+        flat, views = old
+        # the LIST is what an autograd node of a forward pass without its backward yet holds on to (ctx.pregrads); the ELEMENTS
+        # are what became somebody's .grad.  Counts: cache tuple + local + argument (list); list + loop variable + argument (views)
+        if sys.getrefcount(views) == 3 and all(sys.getrefcount(v) == 3 for v in views):
+            if zero:
+                flat.zero_()
+            return flat, views
+    flat = (torch.zeros if zero else torch.empty)(total, device=dev, dtype=torch.float32)
+    views = [torch.as_strided(flat, shp, st, off) for shp, st, off in entries]
+    if not torch.cuda.is_current_stream_capturing():
+        _grad_reuse[ck] = (flat, views)
+    return flat, views
 
 
 def _flat_views(planes, memory_format):
@@ -490,8 +520,8 @@ class RenderFn(torch.autograd.Function):
         lib = _hip.lib()
         half = None if _half_planes is None else list(_half_planes.flat)
         ctx.half = half
-        arr, _ = _hip.make_planes(_split_planes([p.detach() for p in planes]), half=half)
-        dec, keep = _hip.make_decoders([p.detach() for p in params], beta.detach())
+        arr, _ = _hip.make_planes(planes, half=half)
+        dec, keep = _hip.make_decoders(params, beta)
         needs = any(ctx.needs_input_grad)
         if half is not None and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
             raise RuntimeError("mixed precision: gradients with respect to the rays (pose) are not built; detach the rays")
@@ -580,8 +610,8 @@ class RenderFn(torch.autograd.Function):
             ctx.pregrads = None
             if grads is None:
                 _, grads = _alloc_plane_grads(planes)
-        arr, _ = _hip.make_planes(_split_planes([p.detach() for p in planes]), grads, half=ctx.half)
-        dec, keep = _hip.make_decoders([p.detach() for p in params], beta.detach())
+        arr, _ = _hip.make_planes(planes, grads, half=ctx.half)
+        dec, keep = _hip.make_decoders(params, beta)
         if sink is not None:
             # the 12 decoder tensors follow the planes in the flat buffer in C-ABI order = the layout of g_dec
             o = sink.offsets[12]
@@ -642,8 +672,8 @@ class DecodeFn(torch.autograd.Function):
         N = pts.shape[0]
         dev = pts.device
         lib = _hip.lib()
-        arr, _ = _hip.make_planes(_split_planes([p.detach() for p in planes]))
-        dec, keep = _hip.make_decoders([p.detach() for p in params], dummy_beta)
+        arr, _ = _hip.make_planes(planes)
+        dec, keep = _hip.make_decoders(params, dummy_beta)
         needs = any(ctx.needs_input_grad)
         raw = torch.empty(N, 4, device=dev)
         feat = torch.empty(N, 128, device=dev) if needs else None
@@ -668,8 +698,8 @@ class DecodeFn(torch.autograd.Function):
         grads = None
         if need_planes:
             _, grads = _alloc_plane_grads(planes)
-        arr, _ = _hip.make_planes(_split_planes([p.detach() for p in planes]), grads)
-        dec, keep = _hip.make_decoders([p.detach() for p in params], dummy_beta)
+        arr, _ = _hip.make_planes(planes, grads)
+        dec, keep = _hip.make_decoders(params, dummy_beta)
         g_dec = torch.empty(_hip.N_DEC_PARAMS, device=dev)
         g_pts = torch.empty(N, 3, device=dev) if need[0] else None
         ws = torch.empty(lib.eslam_bwd_workspace_bytes(N), dtype=torch.uint8, device=dev)
@@ -693,8 +723,8 @@ def decode_sdf_only(pts, bound6, all_planes, decoders):
     dev = pts.device
     lib = _hip.lib()
     geo = tuple(all_planes[:3]) + tuple(all_planes[:3])
-    arr, _ = _hip.make_planes(tuple([p.detach() for p in grp] for grp in geo))
-    dec, keep = _hip.make_decoders([p.detach() for p in decoder_params(decoders)], beta_tensor(10, dev))
+    arr, _ = _hip.make_planes(geo)
+    dec, keep = _hip.make_decoders(decoder_params(decoders), beta_tensor(10, dev))
     out = torch.empty(N, device=dev)
     with _hip.on_device(dev):
         _hip.check(lib.eslam_decode_fwd(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(pts), N, 1,
@@ -857,9 +887,8 @@ def sample_z(rays_o, rays_d, gt_depth, all_planes, decoders, bound6, truncation,
         if _rng_override is None and _rng_pending.get(dev.index, False):
             state[0] += 1              # the previous samples were never rendered: advance the step here
         ro, rd = _c(rays_o.detach()), _c(rays_d.detach())
-        arr, _ = _hip.make_planes(tuple([p.detach() for p in grp] for grp in all_planes))
-        dec, keep = _hip.make_decoders([p.detach() for p in decoder_params(decoders)],
-                                       beta_tensor(decoders.beta, dev).detach())
+        arr, _ = _hip.make_planes(all_planes)
+        dec, keep = _hip.make_decoders(decoder_params(decoders), beta_tensor(decoders.beta, dev))
         with _hip.on_device(dev):
             _hip.check(lib.eslam_sample_z_all_rng(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(ro), _hip.ptr(rd),
                                                   _hip.ptr(gd), R, n_strat, n_imp, float(truncation), _hip.ptr(t_free),
@@ -883,9 +912,8 @@ def sample_z(rays_o, rays_d, gt_depth, all_planes, decoders, bound6, truncation,
         if u is not None and n_strat >= 3:
             # both samplers in one launch (each wave takes the rule its ray needs)
             ro, rd = _c(rays_o.detach()), _c(rays_d.detach())
-            arr, _ = _hip.make_planes(tuple([p.detach() for p in grp] for grp in all_planes))
-            dec, keep = _hip.make_decoders([p.detach() for p in decoder_params(decoders)],
-                                           beta_tensor(decoders.beta, dev).detach())
+            arr, _ = _hip.make_planes(all_planes)
+            dec, keep = _hip.make_decoders(decoder_params(decoders), beta_tensor(decoders.beta, dev))
             _hip.check(lib.eslam_sample_z_all(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(ro), _hip.ptr(rd),
                                               _hip.ptr(gd), R, n_strat, n_imp, float(truncation), _hip.ptr(t_free),
                                               _hip.ptr(t_surf), _hip.ptr(t_rand), _hip.ptr(t_uni), _hip.ptr(u),
@@ -895,9 +923,8 @@ def sample_z(rays_o, rays_d, gt_depth, all_planes, decoders, bound6, truncation,
                                           _hip.ptr(t_surf), _hip.ptr(t_rand), _hip.ptr(z), st), "eslam_sample_z")
             if u is not None:        # fewer than 3 stratified samples: the importance sampler reports it as unsupported
                 ro, rd = _c(rays_o.detach()), _c(rays_d.detach())
-                arr, _ = _hip.make_planes(tuple([p.detach() for p in grp] for grp in all_planes))
-                dec, keep = _hip.make_decoders([p.detach() for p in decoder_params(decoders)],
-                                               beta_tensor(decoders.beta, dev).detach())
+                arr, _ = _hip.make_planes(all_planes)
+                dec, keep = _hip.make_decoders(decoder_params(decoders), beta_tensor(decoders.beta, dev))
                 _hip.check(lib.eslam_importance_z(arr, ctypes.byref(dec), _hip.make_bound(bound6), _hip.ptr(ro),
                                                   _hip.ptr(rd), _hip.ptr(gd), R, n_strat, n_imp, _hip.ptr(t_free),
                                                   _hip.ptr(t_uni), _hip.ptr(u), _hip.ptr(z), st), "eslam_importance_z")

@@ -36,10 +36,11 @@ class Renderer(object):
         flat_planes = [p for grp in all_planes for p in grp]
         # training calls get a direction-sorted ray order (better L2 locality forward, bundling for the scatter); it only
         # depends on the rays, so it runs on a side stream next to the samplers
-        wants_grad = torch.is_grad_enabled() and (rays_o.requires_grad or rays_d.requires_grad or
-                                                  any(p.requires_grad for p in flat_planes) or
-                                                  any(p.requires_grad for p in decoders.parameters()))
-        planes_grad = torch.is_grad_enabled() and any(p.requires_grad for p in flat_planes)
+        grad_on = torch.is_grad_enabled()
+        planes_grad = grad_on and any(p.requires_grad for p in flat_planes)
+        wants_grad = planes_grad or (grad_on and (rays_o.requires_grad or rays_d.requires_grad or
+                                                  any(p.requires_grad for p in ops.decoder_params(decoders)) or
+                                                  (torch.is_tensor(decoders.beta) and decoders.beta.requires_grad)))
         order = ops.ray_order_async(rays_o, rays_d, flat_planes if planes_grad else None) if wants_grad else None
         z_vals = ops.sample_z(rays_o, rays_d, gt_depth, all_planes, decoders, self._bound6, truncation,
                               self.n_stratified, self.n_importance, self.perturb, _rand)
