@@ -19,7 +19,7 @@ value = ray.samples/s of the whole job = (rays of the job) * S / t_step, t_step 
 roofline = per kernel, against the ceiling that actually bounds it (/opt/skills/guides/MI355X_MICROARCH.md): the forward
 gather against the aggregate L2 rate, the scatter against the chip-wide float-atomic rate, the decoder backward against
 HBM and the fp32 MFMA rate; durations are HIP events on the launch stream, bytes the rocprofv3 PMC counters of THIS build
-(profiles/r02_traffic.json, keyed by the library's hash - stale numbers are dropped, not shown).
+(profiles/r03_traffic.json, keyed by the library's hash and the workload - stale numbers are dropped, not shown).
 cpu_baseline = the CPU oracle (a restatement of the reference's PyTorch path, pinned to the reference by tests/golden)
 timed on this box's host cores on the same workload - a reported baseline, not the target.
 """
@@ -38,6 +38,9 @@ sys.path.insert(0, ROOT)
 
 SINGLE = dict(scene="room0", rays=4096, n_strat=56, n_imp=8, zero_frac=0.0,
               name="BASELINE configs[1]: Replica room0 (synthetic), 4096 rays x 64 samples (56+8)")
+LOWP = dict(scene="freiburg1_desk", rays=5000, n_strat=48, n_imp=8, zero_frac=0.1,
+            name="BASELINE configs[4]: TUM freiburg1_desk (synthetic), 5000 rays x 56 samples (48+8), 10 % depth-less rays, fp16 planes + "
+                 "bf16 MFMA decoders (mixed-precision kernels forward and backward, float32 accumulation and float32 plane gradients)")
 STRONG = dict(scene="scene0000", rays=8192, n_strat=88, n_imp=8, zero_frac=0.1,
               name="BASELINE configs[3]: ScanNet scene0000 (synthetic), ONE batch of 8192 rays x 96 samples (88+8), 10 % "
                    "depth-less rays, ray-sharded")
@@ -64,6 +67,7 @@ def parse():
     ap.add_argument("--weak", action="store_true", help="N > 1: every rank renders its own 4096 x 64 room0 batch")
     ap.add_argument("--strong", action="store_true", help="N = 1: run the configs[3] workload of the N > 1 mode unsharded")
     ap.add_argument("--no-extras", action="store_true", help="skip eager / NCHW / forward-only side measurements")
+    ap.add_argument("--lowp", action="store_true", help="N = 1: BASELINE configs[4], the mixed-precision kernels on freiburg1_desk 5000 x 56")
     return ap.parse_args()
 
 
@@ -233,6 +237,14 @@ def side_measurements(cfg, wl, dev):
         out["nchw_eager_ms_per_step"] = round(timed_median(wn.step, 30, 10, reps=3), 4)
         del gn, wn
 
+        # the same iteration in the trained-like state (planes x 60, SDF-head bias + 0.55: the compositing weights spread over ~20
+        # samples of a ray instead of sitting on the first one, as in the reference's initial state the headline runs in)
+        wt = harness.make_workload(cfg["scene"], cfg["rays"], cfg["n_strat"], cfg["n_imp"], device=dev,
+                                   zero_frac=cfg["zero_frac"], state="trained")
+        gt_ = harness.GraphedStep(wt.step, wt.params())
+        out["trained_state_ms_per_step"] = round(timed(gt_, 50, 10), 4)
+        del gt_, wt
+
         def fwd():
             with torch.no_grad():
                 wl.renderer.render_batch_ray(wl.planes, wl.decoders, wl.rays_d, wl.rays_o, wl.device, wl.truncation,
@@ -246,15 +258,19 @@ def side_measurements(cfg, wl, dev):
     return out
 
 
-def roofline(prof, n, ms_step):
-    """Per-kernel roofline entries + the contract's `roofline` object (the kernel with the longest duration)."""
+def roofline(prof, n, ms_step, tag="4096x64"):
+    """Per-kernel roofline entries + the contract's `roofline` object (the kernel with the longest duration).
+    tag: which workload of profiles/r03_traffic.json the PMC bytes are taken from."""
     traffic = {}
-    traffic_note = "no PMC file for this build (profiles/r02_traffic.json missing or from another library hash): traffic = null"
+    traffic_note = (f"no PMC entry '{tag}' for this build (profiles/r03_traffic.json missing, from another library hash, or another "
+                    "ray count): traffic = null")
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
-        if tj.get("lib_sha256_16") == lib_hash() and tj.get("ray_samples") == n:
-            traffic = tj["kernels"]
-            traffic_note = "profiles/r02_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC passes of this library build on this workload"
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
+        w = tj.get("workloads", {}).get(tag)
+        if tj.get("lib_sha256_16") == lib_hash() and w and w.get("ray_samples") == n:
+            traffic = w["kernels"]
+            traffic_note = (f"profiles/r03_traffic.json['{tag}']: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC passes of this library build "
+                            "on this workload (tools/run_profiles.sh)")
     except Exception:
         pass
 
@@ -265,9 +281,19 @@ def roofline(prof, n, ms_step):
         tr = traffic.get(kernel, {})
         e = {"kernel": kernel, "bound": bound, "avg_kernel_ms": round(prof[kernel], 5), "peak": peak, "unit": unit,
              "algorithmic_bytes_per_launch": alg_bytes, "traffic": tr.get("traffic_bytes")}
-        if bound == "l2":            # every algorithmic byte is a 16-B-per-lane request served by L1/L2
-            e["achieved"] = alg_bytes / t / 1e9
-            e["peak_note"] = (f"aggregate L2 rate; the guide's MEASURED rate of an L2-resident row gather is "
+        if bound == "l2":
+            # what the L2s actually served to the L1s: TCC_HIT + TCC_MISS requests x the request size calibrated in the same PMC
+            # pass (tools/collect_traffic.py).  The algorithmic figure (every texel corner a 16-B-per-lane request) is kept beside it:
+            # the difference is what the per-CU L1s absorbed.
+            rb = tr.get("l2_request_bytes")
+            e["l2_request_bytes"] = rb
+            e["algorithmic_rate_GBs"] = alg_bytes / t / 1e9
+            if rb is not None:
+                e["achieved"] = rb / t / 1e9
+            else:             # no PMC entry for this build: the event-timed rate of the algorithmic requests (an upper bound on the L2 rate)
+                e["achieved"] = alg_bytes / t / 1e9
+                e["achieved_is"] = "algorithmic request bytes / kernel time (no PMC entry for this library build)"
+            e["peak_note"] = (f"aggregate L2 -> L1 rate; the guide's MEASURED rate of an L2-resident row gather is "
                               f"{L2_GATHER_MEASURED_GBS[0] / 1e3:.1f}-{L2_GATHER_MEASURED_GBS[1] / 1e3:.1f} TB/s")
         elif bound == "atomic":      # what the memory side adds: WRITE_SIZE of the atomics (exact for float atomics)
             ab = tr.get("atomic_bytes")
@@ -336,7 +362,10 @@ def run():
 
     from myslam_amd import harness
     strong = (world > 1 and not args.weak) or (world == 1 and args.strong)
-    cfg = STRONG if strong else SINGLE
+    lowp = bool(args.lowp)
+    if lowp and (world > 1 or strong):
+        raise SystemExit("--lowp is the single-GPU configs[4] line")
+    cfg = STRONG if strong else (LOWP if lowp else SINGLE)
     if strong:       # ONE batch, the same on every rank; this rank keeps its contiguous slice
         wl = harness.make_workload(cfg["scene"], cfg["rays"], cfg["n_strat"], cfg["n_imp"], device=dev,
                                    zero_frac=cfg["zero_frac"], seed=0, shard=(rank, world))
@@ -356,6 +385,13 @@ def run():
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         mapper = ShardedMapper(wl)
         step = mapper.step
+    elif lowp:
+        from myslam_amd import lowp as lp, ops as _ops
+        half = lp.HalfPlanes(wl.planes)        # (no optimiser in the timed step: the half copies stay valid)
+
+        def step():
+            with _ops.mixed_precision(half):
+                return wl.step()
     else:
         step = wl.step
     eager_step = step
@@ -406,12 +442,13 @@ def run():
     if rank == 0:
         pct = step_statistics(step) if world == 1 else None        # outside the timed region
         if prof is None:
-            prof = kernel_profile(wl.step, args.profile_iters)      # eager: the HIP events sit inside the C-ABI calls
+            prof = kernel_profile(eager_step, args.profile_iters)   # eager: the HIP events sit inside the C-ABI calls
         n = wl.R * wl.S
         out = {
             "metric": "ray.samples/s (render+bwd)", "value": value, "unit": "ray.samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "dtype": "f16 planes + bf16 MFMA, f32 accumulation" if lowp else "f32", "data": "synthetic",
             "config": {"workload": cfg["name"] + "; mapping iteration: sample + render fwd + loss + bwd (planes+decoders), "
                                    "no optimiser",
                        "rays_of_the_job": total_rays, "rays_this_rank": wl.R, "samples_per_ray": wl.S,
@@ -430,11 +467,11 @@ def run():
                                                                                               else ""))
                        if graphed else "eager launches from Python"},
             # (ray-sharded runs: this rank's kernels on this rank's shard; the PMC bytes are collected for the N = 1 workload only)
-            "roofline": roofline(prof, n, ms_step),
+            "roofline": roofline(prof, n, ms_step, "5000x56_lowp" if lowp else ("8192x96" if strong else "4096x64")),
             "kernel_ms": {k: round(v, 4) for k, v in sorted(prof.items())},
             "step_ms_percentiles": pct,
         }
-        if mapper is None and not args.no_extras:
+        if mapper is None and not lowp and not args.no_extras:
             out.update(side_measurements(cfg, wl, dev))
         if strong and not args.no_extras:
             # the SAME batch unsharded on this one GPU, through the single-GPU step: what a strong-scaling speed-up is against
@@ -455,7 +492,7 @@ def run():
     line = None
     if rank == 0:
         # reported on rank 0 at N=1 only (a host-side baseline does not change with the GPU count)
-        out["cpu_baseline"] = cpu_baseline(wl) if (world == 1 and not strong and not args.no_cpu_baseline) else None
+        out["cpu_baseline"] = cpu_baseline(wl) if (world == 1 and not strong and not lowp and not args.no_cpu_baseline) else None
         if out["cpu_baseline"] is not None:
             # same baseline leg, second device: the port's PyTorch ops run on this GPU instead of the host cores
             try:

@@ -85,7 +85,9 @@ _grad_sink = None
 class grad_sink:
     """Context manager: RenderFn.backward writes plane / decoder / beta gradients into the views of a
     parallel.FlatGrads (params = 12 planes, 12 decoder tensors, [beta]) instead of fresh buffers, so a data-parallel
-    caller can all-reduce one flat buffer with no copy in between."""
+    caller can all-reduce one flat buffer with no copy in between.  Enter it around the backward pass; the FORWARD pass of
+    that call must have run inside this context or inside ops.keep_layout() (either keeps the render call on the Python
+    glue, whose backward looks the sink up - the compiled glue, eslam_torch_ext, hands its gradients to autograd)."""
 
     def __init__(self, flat_grads):
         self.fg = flat_grads
@@ -287,6 +289,62 @@ _FWD_USES_ORDER = os.environ.get("ESLAM_FWD_ORDER", "0") == "1"
 
 
 _fused_loss = None
+
+# The compiled host glue of a render call (myslam_amd/csrc/eslam_torch_ext.cpp, `make torch_ext`): optional - the Python code below
+# is the general path and does the same through ctypes.  ESLAM_TORCH_EXT=0 switches it off.
+_EXT_WANTED = os.environ.get("ESLAM_TORCH_EXT", "1") != "0"
+_ext_mod = False
+
+
+def torch_ext():
+    """The eslam_torch_ext module, or None when it is switched off or not built."""
+    global _ext_mod
+    if _ext_mod is False:
+        _ext_mod = None
+        path = os.path.join(os.path.dirname(_hip.LIB_PATH), "eslam_torch_ext.so")
+        if _EXT_WANTED and os.path.exists(path) and not os.environ.get("ESLAM_HIP_LIB"):
+            import importlib.util
+            _hip.load_library()                      # (the module links against libeslam_hip.so: resolve it from the same file)
+            spec = importlib.util.spec_from_file_location("eslam_torch_ext", path)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            if mod.abi_version() != _hip.ABI_VERSION:
+                raise RuntimeError(f"eslam_torch_ext was built against ABI {mod.abi_version()}, the binding expects {_hip.ABI_VERSION}: "
+                                   "run `make -C myslam_amd/csrc torch_ext`")
+            _ext_mod = mod
+    return _ext_mod
+
+
+def ext_render_ok(rays_o, n_strat, rand):
+    """Whether a render call may take the compiled path: the common case only (see eslam_torch_ext.cpp's header)."""
+    return (rand is None and _USE_KERNEL_RNG and n_strat >= 3 and _half_planes is None and _grad_sink is None and not _keep_layout and
+            _rng_override is None and not _FWD_USES_ORDER and rays_o.is_cuda and torch_ext() is not None)
+
+
+def ext_render(cfg, rays_o, rays_d, gt_depth, beta, flat_planes, dec_params, n_strat, n_imp, fl):
+    """One compiled call: ray order + gradient clear (side stream), sampler, forward (+ the loss's sums), join.  fl: the active
+    ops.fused_loss context or None.  Returns depth, rgb, sdf, z_vals."""
+    dev = rays_o.device
+    seed_v = _rng_seed(dev)
+    state = _rng_state(dev)
+    if _rng_pending.get(dev.index, False):
+        state[0] += 1                  # samples drawn earlier were never rendered
+        _rng_pending[dev.index] = False
+    ext = torch_ext()
+    with _hip.on_device(dev):
+        if fl is None:
+            outs = ext.render(cfg, rays_o, rays_d, gt_depth, beta, flat_planes, dec_params, linspace01(n_strat, dev), linspace01(n_imp, dev),
+                              state, seed_v, _ray_offset)
+        else:
+            mask = fl.ray_mask
+            if mask is not None:
+                mask = _c(mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8))
+            outs = ext.render(cfg, rays_o, rays_d, gt_depth, beta, flat_planes, dec_params, linspace01(n_strat, dev), linspace01(n_imp, dev),
+                              state, seed_v, _ray_offset, fl.gt_color, mask, _loss_scratch(dev, rays_o.shape[0]), fl.acc_out,
+                              list(fl.state.weights5))
+            fl.loss, fl.acc = outs[4], outs[5]
+            fl.value = outs[4].detach()
+    return outs[0], outs[1], outs[2], outs[3]
 
 
 class _LossState:

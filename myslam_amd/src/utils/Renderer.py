@@ -34,6 +34,11 @@ class Renderer(object):
         # planes in the reference's NCHW layout: per-call channels-last scratch copies (gradients flow back through them)
         all_planes = ops.planes_for_kernels(all_planes, n_rays * S)
         flat_planes = [p for grp in all_planes for p in grp]
+        beta = ops.beta_tensor(decoders.beta, rays_o.device)
+        if ops.ext_render_ok(rays_o, self.n_stratified, _rand):
+            # the common case as ONE compiled call (eslam_torch_ext.cpp); everything below is the same sequence through ctypes
+            return ops.ext_render(self._ext_cfg(truncation, decoders), rays_o, rays_d, gt_depth, beta, flat_planes,
+                                  ops.decoder_params(decoders), self.n_stratified, self.n_importance, ops.current_fused_loss())
         # training calls get a direction-sorted ray order (better L2 locality forward, bundling for the scatter); it only
         # depends on the rays, so it runs on a side stream next to the samplers
         grad_on = torch.is_grad_enabled()
@@ -44,7 +49,6 @@ class Renderer(object):
         order = ops.ray_order_async(rays_o, rays_d, flat_planes if planes_grad else None) if wants_grad else None
         z_vals = ops.sample_z(rays_o, rays_d, gt_depth, all_planes, decoders, self._bound6, truncation,
                               self.n_stratified, self.n_importance, self.perturb, _rand)
-        beta = ops.beta_tensor(decoders.beta, rays_o.device)
         # pts are normalised with decoders.bound (decoders.py:138), the importance sampler uses renderer.bound
         bound6 = ops.bound_to_host(decoders.bound)
         fl = ops.current_fused_loss()          # set by render_batch_ray_with_loss
@@ -53,6 +57,24 @@ class Renderer(object):
         if fl is not None:
             fl.loss = outs[3]
         return outs[0], outs[1], outs[2], z_vals
+
+    def _ext_cfg(self, truncation, decoders):
+        """eslam_torch_ext.Config for this renderer and these decoders' bound, rebuilt when anything it holds changes.  Kept out
+        of __getstate__: the Renderer pickles into the reference's tracker / mapper processes (ESLAM.py:246-260)."""
+        b = decoders.bound
+        key = (float(truncation), self.n_stratified, self.n_importance, bool(self.perturb), self._bound6, id(b),
+               b._version if torch.is_tensor(b) else None)
+        hit = self.__dict__.get("_ext_cfg_cache")
+        if hit is None or hit[0] != key:
+            cfg = ops.torch_ext().Config(self.n_stratified, self.n_importance, bool(self.perturb), float(truncation),
+                                         list(self._bound6), list(ops.bound_to_host(b)))
+            hit = self.__dict__["_ext_cfg_cache"] = (key, cfg)
+        return hit[1]
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d.pop("_ext_cfg_cache", None)
+        return d
 
     def render_batch_ray_with_loss(self, all_planes, decoders, rays_d, rays_o, device, truncation, gt_depth, gt_color,
                                    weights, ray_mask=None, _rand=None, acc_out=None):

@@ -208,10 +208,10 @@ def test_rays_marking_contains_every_block_the_backward_touches(scene, zero_frac
     b6 = ops.bound_to_host(wl.scene.bound)
     marked = parallel.mark_rays(None, b6, wl.rays_o, wl.rays_d, wl.gt_depth, wl.truncation, base, n_blocks, planes=wl.planes)
     for it in range(3):                                   # three draws of the jitter / importance samples
-        depth, color, sdf, z = wl.renderer.render_batch_ray(wl.planes, wl.decoders, wl.rays_d, wl.rays_o, dev, wl.truncation,
-                                                            gt_depth=wl.gt_depth)
         fg.flat.zero_()
-        with ops.grad_sink(fg):
+        with ops.grad_sink(fg):                           # (forward AND backward inside: a sink is a property of the whole call)
+            depth, color, sdf, z = wl.renderer.render_batch_ray(wl.planes, wl.decoders, wl.rays_d, wl.rays_o, dev, wl.truncation,
+                                                                gt_depth=wl.gt_depth)
             ((depth * wl._cot[0]).sum() + (color * wl._cot[1]).sum() + (sdf * wl._cot[2]).sum()).backward()
         nz = (fg.flat[:n_blocks * 32].view(-1, 32) != 0).any(1)
         assert int(nz.sum()) > 100

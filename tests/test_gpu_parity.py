@@ -102,8 +102,15 @@ def check_against_fixture(fx, r, rtol=RTOL):
     for k, p in r["dec"].named_parameters():
         assert p.grad is not None, k
         assert hp.rel_err(p.grad.cpu().numpy(), fx["grad:" + k]) <= rtol, k
+        # ... and element by element, with a floor 5x below the max-normalised bar (sums of ~1e5 contributions in float32; a floor
+        # of 1e-5 is missed by 2 of 1024 elements of c_linears.0.weight at 4096 x 64 in the trained-like state, at 1.34x the bar)
+        ok, info = hp.elementwise_close(p.grad.cpu().numpy(), fx["grad:" + k], rtol=rtol, floor=2e-5)
+        assert ok, (k, info)
     assert hp.rel_err(r["ro"].grad.cpu().numpy()[pr], fx["g_rays_o"]) <= rtol
     assert hp.rel_err(r["rd"].grad.cpu().numpy()[pr], fx["g_rays_d"]) <= rtol
+    for name, g, ref in (("g_rays_o", r["ro"].grad, fx["g_rays_o"]), ("g_rays_d", r["rd"].grad, fx["g_rays_d"])):
+        ok, info = hp.elementwise_close(g.cpu().numpy()[pr][has], ref[has], rtol=rtol, floor=1e-5)
+        assert ok, (name, info)
     assert hp.rel_err(r["ro"].grad.double().sum(0).cpu().numpy(), fx["g_rays_o_sum"]) <= rtol
     hp.check_plane_probes(fx, [p.grad for p in hp.flat_planes(r["planes"])], rtol=rtol)
 
@@ -209,6 +216,55 @@ def test_full_gradients_vs_oracle(case):
     assert close(r["rd"].grad.cpu().numpy(), o["rd"].grad, o32["rd"].grad if o32 else None)
     if bool(fx["beta_is_param"]):
         assert close(r["dec"].beta.grad.cpu().numpy(), o["beta"].grad, o32["beta"].grad if o32 else None)
+
+
+@pytest.mark.parametrize("case", ["room0_4096x64_trained_zero10", "scene0000_8192x96_zero10"])
+def test_whole_gradient_tensors_at_full_size(case):
+    """EVERY element of all 12 plane gradients at the BASELINE sizes (4096 x 64 in the trained-like state with 10 % depth-less
+    rays; 8192 x 96 on scene0000) against autograd over the float32 oracle run on this box's host cores, the float64 oracle as
+    the conditioning bound (helpers.plane_grads_close) - the scatter's full-size paths (1536 workgroups in two rounds, the
+    XCD map, counting sort and bitonic fallback) seen through whole tensors, not norms and probes.  Decoder, beta and ray
+    gradients element by element (|a - b| <= 1e-4 |b| + floor * max|b|) beside the max-normalised bar."""
+    from oracle import eslam_oracle as orc
+    from myslam_amd import scene as scn
+    from tests.test_oracle_golden import run_oracle
+    fx = hp.load(case)
+    r = run_hip(fx)
+    o32 = run_oracle(fx, torch.float32)
+    o64 = run_oracle(fx, torch.float64)
+    sc = scn.make_scene(str(fx["scene"]))
+    pts = (o64["ro"].detach()[:, None, :] + o64["rd"].detach()[:, None, :] * o64["z"].detach()[..., None]).reshape(-1, 3)
+    pn = orc.normalize_points(pts, sc.bound.double())
+    amb = hp.ambiguous_samples(pn, tuple([p.detach() for p in grp] for grp in o64["planes"]),
+                               {k: v.detach() for k, v in o64["params"].items()})
+    ok, msg = hp.plane_grads_close([p.grad.cpu().numpy() for p in hp.flat_planes(r["planes"])],
+                                   [p.grad.numpy() for p in hp.flat_planes(o32["planes"])],
+                                   [p.grad.numpy() for p in hp.flat_planes(o64["planes"])], pn, amb, sc.plane_shapes, RTOL)
+    assert ok, (msg, int(amb.sum()))
+    assert int(amb.sum()) <= 2e-3 * amb.numel()               # the exclusion stays an exception
+
+    def elementwise(name, a, b32, b64, floor):
+        """Comparator: the float32 oracle (the reference's arithmetic).  Where the float32 oracle itself is not pinned - it is
+        torch CPU code whose summation order changes with the thread count; on the 200x-weighted SDF terms it sits up to 1e-3
+        from the float64 oracle (conditioning note) - the float64 oracle bounds the comparison instead."""
+        a, b32, b64 = (np.asarray(t, dtype=np.float64) for t in (a, b32, b64))
+        cond = hp.rel_err(b32, b64)
+        assert hp.rel_err(a, b32) <= RTOL or hp.rel_err(a, b64) <= max(RTOL, 1.5 * cond), (name, hp.rel_err(a, b32), hp.rel_err(a, b64), cond)
+        ok, info = hp.elementwise_close(a, b32, rtol=RTOL, floor=floor)
+        if not ok:
+            bad = np.abs(a - b32) > RTOL * np.abs(b32) + floor * np.abs(b32).max()
+            assert (np.abs(a - b64)[bad] <= 1.5 * np.abs(b32 - b64)[bad] + RTOL * np.abs(b64)[bad] + floor * np.abs(b64).max()).all(), (name, info)
+    # floor: 3e-5 of the tensor's largest element - these are float32 sums of 2.6e5 - 7.9e5 float-atomic / MFMA-ordered
+    # contributions; at 1e-5, 2 of the 1024 elements of c_linears.0.weight miss by 1.34x (4096 x 64, trained-like state)
+    for k, p in r["dec"].named_parameters():
+        if k == "beta":
+            continue
+        elementwise(k, p.grad.cpu().numpy(), o32["params"][k].grad.numpy(), o64["params"][k].grad.numpy(), 3e-5)
+    if bool(fx["beta_is_param"]):
+        elementwise("beta", r["dec"].beta.grad.cpu().numpy(), o32["beta"].grad.numpy(), o64["beta"].grad.numpy(), 3e-5)
+    has = fx["gt_depth"] > 0                                    # (depth-less rays sit at importance samples that agree to 1e-4 only)
+    elementwise("rays_o", r["ro"].grad.cpu().numpy()[has], o32["ro"].grad.numpy()[has], o64["ro"].grad.numpy()[has], 3e-5)
+    elementwise("rays_d", r["rd"].grad.cpu().numpy()[has], o32["rd"].grad.numpy()[has], o64["rd"].grad.numpy()[has], 3e-5)
 
 
 @pytest.mark.parametrize("case", ["room0_200x32", "room0_200x40_zero15", "room0_4096x64", "scene0000_8192x96_zero10",
@@ -446,6 +502,63 @@ def test_plane_gradient_buffers_are_reused_only_when_nobody_holds_them():
     (o[0].sum() + o[1].sum()).backward()
     for a, b in zip(twice, [p.grad for p in wl.plane_list]):
         assert hp.rel_err(a.cpu().numpy(), 2 * b.cpu().numpy()) <= 1e-5
+
+
+@pytest.mark.parametrize("layout", ["channels_last", "nchw"])
+def test_compiled_host_glue_equals_python_path(layout, monkeypatch):
+    """eslam_torch_ext (one compiled call for ray order + clear + sampler + forward, one for the backward) against the Python /
+    ctypes glue it shortcuts: same kernels, same random numbers (seed, step, ray index), so the outputs are bit-identical and
+    the gradients equal up to the order of the float atomics - fused loss, separate loss with a ray mask, pose-only gradients
+    (tracking), and a no_grad call."""
+    from myslam_amd import harness, losses, ops
+    if ops.torch_ext() is None:
+        pytest.skip("eslam_torch_ext is not built (make -C myslam_amd/csrc torch_ext)")
+    dev = _dev()
+    ext = ops.torch_ext()
+
+    def run(use_ext, mode):
+        monkeypatch.setattr(ops, "_ext_mod", ext if use_ext else None)
+        wl = harness.make_workload("room0", 1500, 32, 8, device=dev, zero_frac=0.1, state="trained", channels_last=(layout == "channels_last"),
+                                   rays_grad=(mode == "tracking"))
+        ops.seed(77)
+        if mode == "tracking":
+            for p in wl.decoders.parameters():
+                p.requires_grad_(False)
+            planes = tuple([p.detach() for p in grp] for grp in wl.planes)
+        else:
+            planes = wl.planes
+        g = torch.Generator().manual_seed(1)
+        mask = (torch.rand(wl.R, generator=g) > 0.2).to(dev)
+        if mode == "no_grad":
+            with torch.no_grad():
+                d, c, s, z = wl.renderer.render_batch_ray(planes, wl.decoders, wl.rays_d, wl.rays_o, dev, wl.truncation, gt_depth=wl.gt_depth)
+            return [d, c, s, z], []
+        if mode == "fused":
+            d, c, s, z, pre = wl.renderer.render_batch_ray_with_loss(planes, wl.decoders, wl.rays_d, wl.rays_o, dev, wl.truncation, wl.gt_depth,
+                                                                     wl.gt_color, losses.MAPPING_W, ray_mask=mask)
+            loss = losses.mapping_loss(d, c, s, z, wl.gt_depth, wl.gt_color, wl.truncation, precomputed=pre)
+        else:
+            d, c, s, z = wl.renderer.render_batch_ray(planes, wl.decoders, wl.rays_d, wl.rays_o, dev, wl.truncation, gt_depth=wl.gt_depth)
+            loss = (losses.tracking_loss if mode == "tracking" else losses.mapping_loss)(d, c, s, z, wl.gt_depth, wl.gt_color, wl.truncation,
+                                                                                      ray_mask=mask)
+        loss.backward()
+        leaves = [wl.rays_o, wl.rays_d] if mode == "tracking" else wl.params()
+        assert all(p.grad is not None for p in leaves)
+        if mode != "tracking":
+            assert all(p.grad.stride() == p.stride() for p in wl.plane_list)
+        return [d, c, s, z, loss], [p.grad.clone() for p in leaves]
+    try:
+        for mode in ("fused", "separate", "tracking", "no_grad"):
+            oa, ga = run(True, mode)
+            ob, gb = run(False, mode)
+            for a, b in zip(oa[:4], ob[:4]):
+                assert torch.equal(a.detach(), b.detach()), mode
+            if len(oa) > 4:                               # (the loss's sums are float atomics over the workgroups: last bits)
+                assert abs(float(oa[4]) - float(ob[4])) <= 1e-6 * abs(float(ob[4])), mode
+            for a, b in zip(ga, gb):
+                assert hp.rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 1e-5, mode
+    finally:
+        ops.seed(None)
 
 
 def test_cpu_tensors_fail_loudly():
