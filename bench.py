@@ -221,6 +221,9 @@ def side_measurements(cfg, wl, dev):
     from myslam_amd import harness, losses
     out = {}
     try:
+        # a workload of its own: the headline's graph was captured on wl's parameters, which leaves their AccumulateGrad nodes bound to
+        # the capture stream - eager steps on the default stream then pay a stream synchronisation per parameter (0.29 -> 0.57 ms)
+        wl = harness.make_workload(cfg["scene"], cfg["rays"], cfg["n_strat"], cfg["n_imp"], device=dev, zero_frac=cfg["zero_frac"])
         out["eager_ms_per_step"] = round(timed_median(wl.step, 100, 30), 4)  # same step, every launch issued from Python
 
         def reference_shaped():      # the reference loop's own call sequence: render_batch_ray, then the loss, then backward
@@ -232,9 +235,9 @@ def side_measurements(cfg, wl, dev):
         out["eager_separate_loss_ms_per_step"] = round(timed_median(reference_shaped, 100, 30), 4)
         wn = harness.make_workload(cfg["scene"], cfg["rays"], cfg["n_strat"], cfg["n_imp"], device=dev,
                                    zero_frac=cfg["zero_frac"], channels_last=False)
+        out["nchw_eager_ms_per_step"] = round(timed_median(wn.step, 30, 10, reps=3), 4)     # (before the capture: see above)
         gn = harness.GraphedStep(wn.step, wn.params())
         out["nchw_ms_per_step"] = round(timed(gn, 50, 10), 4)            # reference-layout planes, graph replay
-        out["nchw_eager_ms_per_step"] = round(timed_median(wn.step, 30, 10, reps=3), 4)
         del gn, wn
 
         # the same iteration in the trained-like state (planes x 60, SDF-head bias + 0.55: the compositing weights spread over ~20

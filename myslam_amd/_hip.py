@@ -199,7 +199,7 @@ _plane_cache = {}
 _plane_last = None            # (the 12 tensor objects, their data pointers, cache entry) of the last call
 
 
-def make_planes(all_planes, grads=None, dtype=torch.float32, half=None):
+def make_planes(all_planes, grads=None, dtype=torch.float32, half=None, remember=True):
     """all_planes: the reference's 6-tuple of [coarse, fine] lists, or the same 12 tensors as a flat list / tuple
     -> (PlaneArray, keepalive list).  Pass the tensors themselves (Parameters included), not detached copies: the sampler, the
     forward and the backward of one iteration hand over the same 12 objects, and the last call's descriptors are reused when
@@ -251,8 +251,10 @@ def make_planes(all_planes, grads=None, dtype=torch.float32, half=None):
         if len(_plane_cache) > 64:
             _plane_cache.clear()
         hit = _plane_cache[key] = (bytes(arr), [tuple(p.shape) for p in flat], [p.stride() for p in flat])
-    if key is not None and dtype == torch.float32:
-        # (strong references to the 12 tensor objects: while they are held here no other object can take their identity)
+    if key is not None and dtype == torch.float32 and remember:
+        # (strong references to the 12 tensor objects: while they are held here no other object can take their identity.
+        # remember=False for short-lived tensors such as gradient buffers on their way to autograd: a reference kept here would
+        # make AccumulateGrad copy them instead of adopting them)
         _plane_last = (tuple(flat), tuple(p.data_ptr() for p in flat), hit)
     arr = PlaneArray.from_buffer_copy(hit[0])
     if half is not None:

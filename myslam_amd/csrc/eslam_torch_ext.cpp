@@ -326,6 +326,68 @@ public:
     }
 };
 
+// The callers' loss as its own autograd node (src/Mapper.py:110-144,337-346; with ray_mask src/Tracker.py:114-148,197-204): forward =
+// eslam_loss_value (sums, set sizes and the value in one launch), backward = eslam_loss_grad scaled by the incoming gradient.
+class LossNode : public torch::autograd::Function<LossNode> {
+public:
+    struct IO {
+        Tensor z, gt_depth, gt_color, ray_mask, scratch;
+        double truncation = 0.0;
+        std::vector<float> w5;
+    };
+    static Tensor forward(AutogradContext* ctx, const Tensor& depth_in, const Tensor& rgb_in, const Tensor& sdf_in, const IO& io) {
+        for (const Tensor* t : {&depth_in, &rgb_in, &sdf_in, &io.z, &io.gt_depth, &io.gt_color})
+            TORCH_CHECK(t->is_cuda() && t->scalar_type() == at::kFloat, "loss: expected float32 tensors on the GPU; the HIP render path has no CPU fallback");
+        const Tensor depth = depth_in.detach().contiguous(), rgb = rgb_in.detach().contiguous(), sdf = sdf_in.detach().contiguous();
+        const Tensor z = io.z.detach().contiguous(), gd = io.gt_depth.detach().contiguous(), gc = io.gt_color.detach().contiguous();
+        const int64_t R = sdf.size(0), S = sdf.size(1);
+        const int dev = sdf.get_device();
+        c10::hip::HIPGuard guard(dev);
+        hipStream_t st = c10::hip::getCurrentHIPStream(dev).stream();
+        Tensor acc = at::empty({16}, sdf.options()), loss = at::empty({}, sdf.options());
+        const uint8_t* mask = io.ray_mask.defined() ? (const uint8_t*)io.ray_mask.data_ptr() : nullptr;
+        check(eslam_loss_value(depth.data_ptr<float>(), rgb.data_ptr<float>(), sdf.data_ptr<float>(), z.data_ptr<float>(), gd.data_ptr<float>(),
+                               gc.data_ptr<float>(), (int)R, (int)S, io.truncation, io.w5.data(), mask, io.scratch.data_ptr<float>(),
+                               acc.data_ptr<float>(), loss.data_ptr<float>(), st), "eslam_loss_value");
+        ctx->save_for_backward({depth, rgb, sdf, z, gd, gc, acc});
+        if (io.ray_mask.defined()) ctx->saved_data["ray_mask"] = io.ray_mask;
+        ctx->saved_data["truncation"] = io.truncation;
+        ctx->saved_data["w5"] = std::vector<double>(io.w5.begin(), io.w5.end());
+        return loss;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g) {
+        auto sv = ctx->get_saved_variables();
+        TORCH_CHECK(sv.size() == 7, "eslam_torch_ext: loss node lost its saved tensors");
+        const Tensor &depth = sv[0], &rgb = sv[1], &sdf = sv[2], &z = sv[3], &gd = sv[4], &gc = sv[5], &acc = sv[6];
+        const int64_t R = sdf.size(0), S = sdf.size(1);
+        const int dev = sdf.get_device();
+        c10::hip::HIPGuard guard(dev);
+        hipStream_t st = c10::hip::getCurrentHIPStream(dev).stream();
+        auto opt = sdf.options();
+        Tensor g_depth = at::empty({R}, opt), g_rgb = at::empty({R, 3}, opt), g_sdf = at::empty({R, S}, opt);
+        const Tensor up = g[0].detach().reshape({1}).to(at::kFloat).contiguous();
+        auto w5d = ctx->saved_data["w5"].toDoubleVector();
+        float w5[5];
+        for (int i = 0; i < 5; ++i) w5[i] = (float)w5d[i];
+        const uint8_t* mask = ctx->saved_data.count("ray_mask") ? (const uint8_t*)ctx->saved_data["ray_mask"].toTensor().data_ptr() : nullptr;
+        check(eslam_loss_grad(depth.data_ptr<float>(), rgb.data_ptr<float>(), sdf.data_ptr<float>(), z.data_ptr<float>(), gd.data_ptr<float>(),
+                              gc.data_ptr<float>(), (int)R, (int)S, ctx->saved_data["truncation"].toDouble(), w5, mask, acc.data_ptr<float>(),
+                              nullptr, g_depth.data_ptr<float>(), g_rgb.data_ptr<float>(), g_sdf.data_ptr<float>(), up.data_ptr<float>(), st),
+              "eslam_loss_grad");
+        return {g_depth, g_rgb, g_sdf, Tensor()};
+    }
+};
+
+Tensor mapping_loss(const Tensor& depth, const Tensor& rgb, const Tensor& sdf, const Tensor& z, const Tensor& gt_depth, const Tensor& gt_color,
+                    double truncation, const std::vector<double>& weights5, const c10::optional<Tensor>& ray_mask, const Tensor& scratch) {
+    TORCH_CHECK(weights5.size() == 5 && sdf.dim() == 2, "mapping_loss: 5 weights and sdf [R,S] expected");
+    LossNode::IO io;
+    io.z = z; io.gt_depth = gt_depth; io.gt_color = gt_color; io.scratch = scratch; io.truncation = truncation;
+    io.w5.assign(weights5.begin(), weights5.end());
+    if (ray_mask.has_value()) io.ray_mask = ray_mask->contiguous();
+    return LossNode::apply(depth, rgb, sdf, io);
+}
+
 // depth, rgb, sdf, z_vals[, loss value, acc] = render(...)
 std::vector<Tensor> render(const Config& cfg, const Tensor& rays_o, const Tensor& rays_d, const Tensor& gt_depth, const Tensor& beta,
                            const std::vector<Tensor>& planes, const std::vector<Tensor>& params, const Tensor& t_free, const Tensor& t_surf,
@@ -377,5 +439,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("params"), py::arg("t_free"), py::arg("t_surf"), py::arg("rng_state"), py::arg("seed"), py::arg("ray_offset"),
           py::arg("gt_color") = py::none(), py::arg("ray_mask") = py::none(), py::arg("scratch") = py::none(), py::arg("acc_out") = py::none(),
           py::arg("weights5") = std::vector<double>());
+    m.def("mapping_loss", &mapping_loss, py::arg("depth"), py::arg("rgb"), py::arg("sdf"), py::arg("z_vals"), py::arg("gt_depth"),
+          py::arg("gt_color"), py::arg("truncation"), py::arg("weights5"), py::arg("ray_mask"), py::arg("scratch"));
     m.def("abi_version", []() { return eslam_abi_version(); });
 }

@@ -23,8 +23,19 @@ def mapping_loss(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weig
         if precomputed.loss is None:
             raise RuntimeError("mapping_loss: the fused_loss context has not seen a forward pass")
         return precomputed.loss              # an output of the render's own autograd node (ops.RenderFn)
-    return ops.MappingLossFn.apply(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights, ray_mask, None,
-                                   None)
+    return _loss(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights, ray_mask)
+
+
+def _loss(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights, mask):
+    """The loss node: compiled (eslam_torch_ext.mapping_loss) when the extension is there, else the Python Function - the same
+    two launches either way."""
+    ext = ops.torch_ext()
+    if ext is not None and sdf.is_cuda and sdf.dim() == 2:
+        if mask is not None:
+            mask = mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)
+        return ext.mapping_loss(depth, color, sdf, z_vals, gt_depth, gt_color, float(truncation), [float(v) for v in weights], mask,
+                                ops._loss_scratch(sdf.device, sdf.shape[0]))
+    return ops.MappingLossFn.apply(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights, mask, None, None)
 
 
 def tracking_loss(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights=TRACKING_W, ray_mask=None):
@@ -41,4 +52,4 @@ def tracking_loss(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, wei
             srt = torch.where(ray_mask, err, torch.full_like(err, float("inf"))).sort().values
             k = ((ray_mask.sum() - 1).clamp(min=0) // 2).reshape(1)
             mask = ray_mask & (err < 10 * srt.gather(0, k))
-    return ops.MappingLossFn.apply(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights, mask, None, None)
+    return _loss(depth, color, sdf, z_vals, gt_depth, gt_color, truncation, weights, mask)

@@ -159,8 +159,8 @@ def _flat_views(planes, memory_format):
 def _relayout(src, dst, field):
     """eslam_planes_relayout between two lists of 12 tensors (field 0: values; field 1: the tensors are gradients)."""
     dev = src[0].device
-    a, _ = _hip.make_planes(_split_planes(src), src if field else None)
-    b, _ = _hip.make_planes(_split_planes(dst), dst if field else None)
+    a, _ = _hip.make_planes(_split_planes(src), src if field else None, remember=False)
+    b, _ = _hip.make_planes(_split_planes(dst), dst if field else None, remember=False)
     with _hip.on_device(dev):
         _hip.check(_hip.lib().eslam_planes_relayout(a, b, int(field), _hip.stream_handle(dev)), "eslam_planes_relayout")
 
