@@ -255,7 +255,8 @@ __global__ __launch_bounds__(1024) void ray_order_kernel(const float* __restrict
 // ---------------------------------------------------------------------------------------------------------
 // NT threads per workgroup, BM = 4*NT samples per workgroup (power of two).
 //   DBG: 0 production; 1 walk without atomics; 2 stop after the sort; 3 = 1 without the g_feat row loads; 4 = 3 without the
-//   LDS weight reads (profiling only, tools/scatter_anatomy.sh)
+//   LDS weight reads; 5 = 3 WITH the atomics (atomics, but no loads queued behind them); 6 = 0 with plain stores in place of
+//   the atomics (profiling only, tools/scatter_anatomy.sh; 5 and 6 write garbage into the gradients)
 //   (Round 2 had the kernel's two halves - cells + sort / walk - as separately launchable phases, the first one beside the
 //   forward kernel on a side stream: 0.369 vs 0.323 ms per step, DESIGN.md section 10.  Removed in round 3.)
 #ifndef SC_STAMPS
@@ -596,10 +597,15 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
                         atomicAdd((float*)((char*)grad + o1), __builtin_nanf(""));
                     }
                 }
-            } else if (dbg_mode == 0) {
+            } else if (dbg_mode == 0 || dbg_mode == 5) {
                 if (!lower_half_only || hx == 0) {
                     atomicAdd((float*)(gbytes + o0), (float)acc0);
                     atomicAdd((float*)(gbytes + o1), (float)acc1);
+                }
+            } else if (dbg_mode == 6) {
+                if (!lower_half_only || hx == 0) {
+                    *(float*)(gbytes + o0) = (float)acc0;
+                    *(float*)(gbytes + o1) = (float)acc1;
                 }
             } else if ((float)acc0 == 1.2345e30f) *(float*)(gbytes + o0) = (float)acc1;      // profiling only: walk without atomics
         }
@@ -631,7 +637,7 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
 #define LOAD_HALF(buf, rec, half)                                                             \
     _Pragma("unroll") for (int t = 0; t < WALK_N; ++t) {                                      \
         const int rowb = __builtin_amdgcn_readlane((rec).row, (half) * WALK_N + t);           \
-        buf[t] = (dbg_mode >= 3) ? __int_as_float(rowb)                                       \
+        buf[t] = (dbg_mode >= 3 && dbg_mode <= 5) ? __int_as_float(rowb)                                       \
                                  : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grsrc, cvoff, rowb, 0)); \
     }
 #define WALK_HALF(buf, rec, half, ebase)                                                      \
@@ -745,18 +751,35 @@ extern "C" int eslam_ray_order(const float* rays_o, const float* rays_d, int R, 
 }
 
 // perm: ray order to bundle by (render mode), or NULL for the given order
-static int scatter_bundle_size(int S, bool render, int* bm_out) {
-    static const int bm = env_int("ESLAM_SC_BUNDLE", 2048);        // profiling switch: 1024 or 2048
-    *bm_out = bm == 1024 ? 1024 : 2048;
-    return *bm_out / (render ? S : 64);
+// Samples per workgroup (*bm_out).  2048 (512 threads x 4) halve the cell flushes of 1024; a batch whose 2048-sample bundles
+// make fewer than SC_SMALL_WGS workgroups (most CUs would idle while a few walk 256 entries per wave) is cut into
+// 1024-sample bundles walked by the same 512 threads (2 samples per thread, 128 sorted entries per wave): twice the
+// workgroups, half the walk.  Measured (profiles/r03/c_*): 200 x 32 (84 workgroups) 50.9 -> 30.6 us; 1024 x 64 (384) 47.2 ->
+// 50.6, 1024 x 96 (588) 55.1 -> 68.5, 2048 x 64 75.5 -> 89.7: from a few hundred workgroups on the kernel is throughput-bound
+// and the extra cell flushes of the smaller bundles cost more than the shorter walk gains.  ESLAM_SC_BUNDLE = 2048 / 1024 forces one of the two; 256 = the old 256-thread form of 1024
+// (profiling only).
+#ifndef SC_SMALL_WGS
+#define SC_SMALL_WGS 192
+#endif
+static int scatter_bundle_size(int per, int nunits, int* bm_out) {
+    static const int forced = env_int("ESLAM_SC_BUNDLE", 0);
+    int bm = forced == 1024 || forced == 2048 || forced == 256 ? forced : 0;
+    if (eslam_deterministic()) bm = 2048;              // (the fixed-point kernel is instantiated for 2048 only)
+    if (bm == 0) {
+        const int big = 2048 / per;
+        const int nb = big > 0 ? (nunits + big - 1) / big : nunits;
+        bm = (nb * NPL <= SC_SMALL_WGS && 1024 / per >= 1) ? 1024 : 2048;
+    }
+    *bm_out = bm;
+    return (bm == 2048 ? 2048 : 1024) / per;
 }
 
 // whether the scatter launch of this mode can also run the decoder-gradient slab reduction (the production render path: one
 // kernel, XCD-mapped 1-D grid, 512 threads); the stand-alone dec_grad_reduce_kernel covers the rest
 bool eslam_scatter_can_reduce(bool render) {
-    static const int xcd_map = env_int("ESLAM_SC_XCDMAP", 1), dbg_mode = env_int("ESLAM_SC_MODE", 0), bm = env_int("ESLAM_SC_BUNDLE", 2048);
+    static const int xcd_map = env_int("ESLAM_SC_XCDMAP", 1), dbg_mode = env_int("ESLAM_SC_MODE", 0), bm = env_int("ESLAM_SC_BUNDLE", 0);
     static const int off = env_int("ESLAM_SC_NO_REDUCE", 0);
-    return render && !eslam_deterministic() && xcd_map && dbg_mode == 0 && bm != 1024 && !off;
+    return render && !eslam_deterministic() && xcd_map && dbg_mode == 0 && bm != 256 && !off;
 }
 
 int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float* rays_o, const float* rays_d,
@@ -788,7 +811,7 @@ int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float*
     const int per = render ? S : 64;
     // 2048 samples per workgroup (512 threads) halve the number of cell flushes of 1024; S up to 256 -> >= 8 rays
     int bm;
-    const int bundle = scatter_bundle_size(per, render, &bm);
+    const int bundle = scatter_bundle_size(per, nunits, &bm);
     for (int i = 0; i < NPL; ++i)
         if ((int64_t)planes[i].w * planes[i].h >= ((1 << 21) - 2)) {
             eslam_set_error("scatter: plane %d has %d x %d cells, limit 2^21", i, planes[i].h, planes[i].w);
@@ -810,8 +833,8 @@ int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float*
         red_blocks = (2 * DEC_RED_COLBLOCKS + 7) / 8 * 8;
         grid.x += red_blocks;
     }
-#define LAUNCH_SC(RD, DB, NTv, PERM, SS)                                                                                   \
-    hipLaunchKernelGGL((scatter_sort_kernel<RD, DB, NTv, false>), grid, dim3(NTv), 0, st, ps, bnd, rays_o, rays_d, z_or_pts, \
+#define LAUNCH_SC(RD, DB, NTv, PERM, SS, ...)                                                                              \
+    hipLaunchKernelGGL((scatter_sort_kernel<RD, DB, NTv, false, ##__VA_ARGS__>), grid, dim3(NTv), 0, st, ps, bnd, rays_o, rays_d, z_or_pts, \
                        PERM, (int)R, SS, g_feat, bundle, counting, nbundles, xcd_map, (long long*)nullptr, ShadowOff{}, \
                        red_args, red_blocks)
     if (eslam_deterministic()) {
@@ -882,10 +905,14 @@ int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float*
         else if (dbg_mode == 2) LAUNCH_SC(true, 2, 512, perm, S);
         else if (dbg_mode == 3) LAUNCH_SC(true, 3, 512, perm, S);
         else if (dbg_mode == 4) LAUNCH_SC(true, 4, 512, perm, S);
-        else if (bm == 1024) LAUNCH_SC(true, 0, 256, perm, S);
+        else if (dbg_mode == 5) LAUNCH_SC(true, 5, 512, perm, S);
+        else if (dbg_mode == 6) LAUNCH_SC(true, 6, 512, perm, S);
+        else if (bm == 256) LAUNCH_SC(true, 0, 256, perm, S);
+        else if (bm == 1024) LAUNCH_SC(true, 0, 512, perm, S, 2);
         else LAUNCH_SC(true, 0, 512, perm, S);
     } else {
-        LAUNCH_SC(false, 0, 512, (const int*)nullptr, 64);
+        if (bm == 1024) LAUNCH_SC(false, 0, 512, (const int*)nullptr, 64, 2);
+        else LAUNCH_SC(false, 0, 512, (const int*)nullptr, 64);
     }
 #undef LAUNCH_SC
     return eslam_check_launch("scatter_sort_kernel");

@@ -93,8 +93,10 @@ struct LossArgs {                  // the fused mapping loss (ops.fused_loss); g
     std::vector<float> weights5;
 };
 
-// Flat gradient buffer + 12 views with the planes' own strides (autograd adopts the views without a copy)
-std::pair<Tensor, std::vector<Tensor>> alloc_plane_grads(const std::vector<Tensor>& planes) {
+// Flat buffer (uninitialised) + 12 views of the planes' shapes: with the planes' own strides (autograd adopts such views as
+// gradients without a copy), or dense channels-last / NCHW-contiguous whatever the planes are
+enum class Layout { same, channels_last, nchw };
+std::pair<Tensor, std::vector<Tensor>> alloc_plane_grads(const std::vector<Tensor>& planes, Layout layout = Layout::same) {
     int64_t total = 0;
     for (auto& p : planes) total += p.numel();
     Tensor flat = at::empty({total}, planes[0].options());
@@ -103,10 +105,21 @@ std::pair<Tensor, std::vector<Tensor>> alloc_plane_grads(const std::vector<Tenso
     int64_t off = 0;
     for (auto& p : planes) {
         TORCH_CHECK(p.is_contiguous() || p.is_contiguous(at::MemoryFormat::ChannelsLast), "planes must be dense (contiguous or channels_last)");
-        views.push_back(at::as_strided(flat, p.sizes(), p.strides(), off));
+        const int64_t c = p.size(1), h = p.size(2), w = p.size(3);
+        if (layout == Layout::same) views.push_back(at::as_strided(flat, p.sizes(), p.strides(), off));
+        else if (layout == Layout::channels_last) views.push_back(at::as_strided(flat, p.sizes(), {c * h * w, 1, c * w, c}, off));
+        else views.push_back(at::as_strided(flat, p.sizes(), {c * h * w, h * w, w, 1}, off));
         off += p.numel();
     }
     return {flat, views};
+}
+
+// eslam_planes_relayout between two lists of 12 tensors (field 0: as values, 1: as gradients)
+void relayout(const std::vector<Tensor>& src, const std::vector<Tensor>& dst, int field, hipStream_t st) {
+    eslam_plane_t a[ESLAM_N_PLANES], b[ESLAM_N_PLANES];
+    fill_planes(src, field ? &src : nullptr, a);
+    fill_planes(dst, field ? &dst : nullptr, b);
+    check(eslam_planes_relayout(a, b, field, st), "eslam_planes_relayout");
 }
 
 class RenderNode : public torch::autograd::Function<RenderNode> {
@@ -119,6 +132,10 @@ public:
         int64_t ray_offset = 0;
         LossArgs loss;
         bool needs = false, planes_grad = false;      // anything / the planes want a gradient (under the CALLER's grad mode)
+        // planes in the reference's NCHW layout (src/ESLAM.py:199-210) and a batch large enough to pay for two copies of them: the
+        // kernels run on channels-last scratch filled here, and the backward hands the gradients back in the planes' own strides
+        // (what ops.ChannelsLastFn does around the Python path; nothing is kept across calls: src/Mapper.py:254-266)
+        bool relayout = false;
     };
 
     static variable_list forward(AutogradContext* ctx, at::TensorList in, const IO& io) {
@@ -147,6 +164,11 @@ public:
             raw_rgb = at::empty({R, S, 3}, opt);
             feat = at::empty({R * S, 128}, opt);
             perm = at::empty({R}, opt.dtype(at::kInt));
+        }
+        if (io.relayout && R > 0) {
+            auto cl = alloc_plane_grads(planes, Layout::channels_last);
+            relayout(planes, cl.second, 0, st);
+            planes = std::move(cl.second);
         }
         eslam_plane_t pd[ESLAM_N_PLANES];
         fill_planes(planes, nullptr, pd);
@@ -206,6 +228,7 @@ public:
             saved.insert(saved.end(), params.begin(), params.end());
             ctx->save_for_backward(saved);
             ctx->saved_data["with_loss"] = with_loss;
+            ctx->saved_data["relayout"] = io.relayout && R > 0;
             ctx->saved_data["truncation"] = io.cfg.truncation;
             ctx->saved_data["bound"] = std::vector<double>(io.cfg.bound_decode.begin(), io.cfg.bound_decode.end());
             if (planes_grad) ctx->saved_data["grad_views"] = grad_views;
@@ -221,27 +244,18 @@ public:
         return out;
     }
 
-#define DBG(x) do { if (getenv("ESLAM_EXT_DEBUG")) { fprintf(stderr, "[ext bwd] %s\n", x); fflush(stderr); } } while (0)
     static variable_list backward(AutogradContext* ctx, variable_list g) {
-        DBG("enter");
         auto saved = ctx->get_saved_variables();
-        DBG("saved");
-        if (getenv("ESLAM_EXT_DEBUG")) { fprintf(stderr, "[ext bwd] %zu saved variables, %zu incoming gradients\n", saved.size(), g.size()); fflush(stderr); }
         TORCH_CHECK(saved.size() == 35, "eslam_torch_ext: expected 35 saved tensors, got ", saved.size());
         const Tensor &rays_o = saved[0], &rays_d = saved[1], &z = saved[2], &sdf = saved[3], &raw_rgb = saved[4], &feat = saved[5],
                      &perm = saved[6], &beta = saved[7], &depth = saved[8], &rgb = saved[9], &gd = saved[10];
         std::vector<Tensor> planes(saved.begin() + 11, saved.begin() + 23), params(saved.begin() + 23, saved.begin() + 35);
-        DBG("vectors");
         const int64_t R = z.size(0), S = z.size(1);
         const int dev = rays_o.get_device();
-        DBG("sizes");
         c10::hip::HIPGuard guard(dev);
         hipStream_t st = c10::hip::getCurrentHIPStream(dev).stream();
-        DBG("stream");
         const bool with_loss = ctx->saved_data["with_loss"].toBool();
-        DBG("with_loss");
         const bool need_ro = ctx->needs_input_grad(0), need_rd = ctx->needs_input_grad(1), need_beta = ctx->needs_input_grad(2);
-        DBG("needs");
         bool need_planes = false, need_dec = false;
         for (int i = 0; i < 12; ++i) need_planes = need_planes || ctx->needs_input_grad(3 + i);
         for (int i = 0; i < 12; ++i) need_dec = need_dec || ctx->needs_input_grad(15 + i);
@@ -258,10 +272,8 @@ public:
                 grad_views = std::move(gv.second);
             }
         }
-        DBG("grad views");
         eslam_plane_t pd[ESLAM_N_PLANES];
         fill_planes(planes, need_planes ? &grad_views : nullptr, pd);
-        DBG("planes filled");
         eslam_decoders_t dd;
         fill_decoders(params, beta, &dd);
         Tensor g_dec = need_dec ? at::empty({ESLAM_N_DEC_PARAMS}, opt) : Tensor();
@@ -271,9 +283,7 @@ public:
             if (need_dec) g_dec.zero_();
             if (need_beta) g_beta.zero_();
         }
-        DBG("outputs allocated");
         Tensor ws = at::empty({eslam_bwd_workspace_bytes(R * S)}, opt.dtype(at::kByte));
-        DBG("workspace");
         // keep contiguous copies alive across the launch
         Tensor gdep = g[0].defined() ? g[0].contiguous() : Tensor(), grgb = g[1].defined() ? g[1].contiguous() : Tensor(),
                gsdf = g[2].defined() ? g[2].contiguous() : Tensor();
@@ -306,11 +316,15 @@ public:
                                    need_rays ? g_ro.data_ptr<float>() : nullptr, need_rays ? g_rd.data_ptr<float>() : nullptr,
                                    perm.data_ptr<int32_t>(), ws.data_ptr(), st), "eslam_render_bwd");
         }
-        DBG("kernels enqueued");
         variable_list out(28);             // 27 tensor inputs + the IO argument's (undefined) slot
         if (need_ro) out[0] = g_ro;
         if (need_rd) out[1] = g_rd;
         if (need_beta) out[2] = g_beta;
+        if (need_planes && ctx->saved_data["relayout"].toBool()) {       // channels-last scratch gradients -> the planes' NCHW strides
+            auto nchw = alloc_plane_grads(grad_views, Layout::nchw);
+            relayout(grad_views, nchw.second, 1, st);
+            grad_views = std::move(nchw.second);
+        }
         for (int i = 0; i < 12; ++i)
             if (need_planes && ctx->needs_input_grad(3 + i)) out[3 + i] = grad_views[i];
         if (need_dec) {
@@ -321,7 +335,6 @@ public:
                 off += sizes[i];
             }
         }
-        DBG("returning");
         return out;
     }
 };
@@ -393,13 +406,13 @@ std::vector<Tensor> render(const Config& cfg, const Tensor& rays_o, const Tensor
                            const std::vector<Tensor>& planes, const std::vector<Tensor>& params, const Tensor& t_free, const Tensor& t_surf,
                            const Tensor& rng_state, uint64_t seed, int64_t ray_offset, const c10::optional<Tensor>& gt_color,
                            const c10::optional<Tensor>& ray_mask, const c10::optional<Tensor>& scratch, const c10::optional<Tensor>& acc_out,
-                           const std::vector<double>& weights5) {
+                           const std::vector<double>& weights5, bool relayout) {
     TORCH_CHECK(cfg.n_strat >= 3 && cfg.bound_sample.size() == 6 && cfg.bound_decode.size() == 6, "Config not initialised");
     TORCH_CHECK(planes.size() == 12 && params.size() == 12, "expected 12 planes and 12 decoder tensors");
     RenderNode::IO io;
     io.cfg = cfg;
     io.gt_depth = gt_depth; io.t_free = t_free; io.t_surf = t_surf; io.rng_state = rng_state;
-    io.seed = seed; io.ray_offset = ray_offset;
+    io.seed = seed; io.ray_offset = ray_offset; io.relayout = relayout;
     TORCH_CHECK(t_free.numel() == cfg.n_strat && t_surf.numel() == cfg.n_imp && rng_state.scalar_type() == at::kInt, "bad sampler tensors");
     if (gt_color.has_value()) {
         TORCH_CHECK(scratch.has_value() && weights5.size() == 5, "the fused loss needs its scratch and 5 weights");
@@ -438,7 +451,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("render", &render, py::arg("cfg"), py::arg("rays_o"), py::arg("rays_d"), py::arg("gt_depth"), py::arg("beta"), py::arg("planes"),
           py::arg("params"), py::arg("t_free"), py::arg("t_surf"), py::arg("rng_state"), py::arg("seed"), py::arg("ray_offset"),
           py::arg("gt_color") = py::none(), py::arg("ray_mask") = py::none(), py::arg("scratch") = py::none(), py::arg("acc_out") = py::none(),
-          py::arg("weights5") = std::vector<double>());
+          py::arg("weights5") = std::vector<double>(), py::arg("relayout") = false);
     m.def("mapping_loss", &mapping_loss, py::arg("depth"), py::arg("rgb"), py::arg("sdf"), py::arg("z_vals"), py::arg("gt_depth"),
           py::arg("gt_color"), py::arg("truncation"), py::arg("weights5"), py::arg("ray_mask"), py::arg("scratch"));
     m.def("abi_version", []() { return eslam_abi_version(); });

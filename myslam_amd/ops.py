@@ -220,17 +220,24 @@ class keep_layout:
         _keep_layout -= 1
 
 
+def wants_relayout(all_planes, n_points):
+    """Whether this call should run on per-call channels-last copies of the planes: they are in the reference's NCHW layout
+    and the batch is large enough to pay for the copies."""
+    flat = [p for grp in all_planes for p in grp]
+    if _keep_layout or _RELAYOUT_MIN_POINTS < 0 or n_points < _RELAYOUT_MIN_POINTS or len(flat) != 12:
+        return False
+    if all(p.dim() == 4 and p.shape[2] * p.shape[3] > 1 and p.is_contiguous(memory_format=torch.channels_last) for p in flat):
+        return False
+    # (anything else: let the kernels' own validation speak)
+    return all(p.is_cuda and p.dtype == torch.float32 and p.dim() == 4 and p.is_contiguous() for p in flat)
+
+
 def planes_for_kernels(all_planes, n_points):
     """all_planes as the kernels should see them: unchanged when channels-last (or the batch is small), else per-call
     channels-last scratch copies that carry the gradient back to the caller's planes (ChannelsLastFn)."""
-    flat = [p for grp in all_planes for p in grp]
-    if _keep_layout or _RELAYOUT_MIN_POINTS < 0 or n_points < _RELAYOUT_MIN_POINTS or len(flat) != 12:
+    if not wants_relayout(all_planes, n_points):
         return all_planes
-    if all(p.dim() == 4 and p.shape[2] * p.shape[3] > 1 and p.is_contiguous(memory_format=torch.channels_last) for p in flat):
-        return all_planes
-    if not all(p.is_cuda and p.dtype == torch.float32 and p.dim() == 4 and p.is_contiguous() for p in flat):
-        return all_planes                     # let the kernels' own validation speak
-    return _split_planes(ChannelsLastFn.apply(*flat))
+    return _split_planes(ChannelsLastFn.apply(*[p for grp in all_planes for p in grp]))
 
 
 _DEC_SIZES = [16 * 64, 16, 16 * 16, 16, 16, 1, 16 * 64, 16, 16 * 16, 16, 48, 3]
@@ -321,9 +328,9 @@ def ext_render_ok(rays_o, n_strat, rand):
             _rng_override is None and not _FWD_USES_ORDER and rays_o.is_cuda and torch_ext() is not None)
 
 
-def ext_render(cfg, rays_o, rays_d, gt_depth, beta, flat_planes, dec_params, n_strat, n_imp, fl):
-    """One compiled call: ray order + gradient clear (side stream), sampler, forward (+ the loss's sums), join.  fl: the active
-    ops.fused_loss context or None.  Returns depth, rgb, sdf, z_vals."""
+def ext_render(cfg, rays_o, rays_d, gt_depth, beta, flat_planes, dec_params, n_strat, n_imp, fl, relayout=False):
+    """One compiled call: [planes -> channels-last scratch when `relayout`,] ray order + gradient clear (side stream), sampler,
+    forward (+ the loss's sums), join.  fl: the active ops.fused_loss context or None.  Returns depth, rgb, sdf, z_vals."""
     dev = rays_o.device
     seed_v = _rng_seed(dev)
     state = _rng_state(dev)
@@ -334,14 +341,14 @@ def ext_render(cfg, rays_o, rays_d, gt_depth, beta, flat_planes, dec_params, n_s
     with _hip.on_device(dev):
         if fl is None:
             outs = ext.render(cfg, rays_o, rays_d, gt_depth, beta, flat_planes, dec_params, linspace01(n_strat, dev), linspace01(n_imp, dev),
-                              state, seed_v, _ray_offset)
+                              state, seed_v, _ray_offset, relayout=relayout)
         else:
             mask = fl.ray_mask
             if mask is not None:
                 mask = _c(mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8))
             outs = ext.render(cfg, rays_o, rays_d, gt_depth, beta, flat_planes, dec_params, linspace01(n_strat, dev), linspace01(n_imp, dev),
                               state, seed_v, _ray_offset, fl.gt_color, mask, _loss_scratch(dev, rays_o.shape[0]), fl.acc_out,
-                              list(fl.state.weights5))
+                              list(fl.state.weights5), relayout)
             fl.loss, fl.acc = outs[4], outs[5]
             fl.value = outs[4].detach()
     return outs[0], outs[1], outs[2], outs[3]

@@ -31,14 +31,15 @@ class Renderer(object):
         if n_rays == 0:
             e = rays_o.new_empty
             return e(0), e(0, 3), e(0, S), e(0, S)
-        # planes in the reference's NCHW layout: per-call channels-last scratch copies (gradients flow back through them)
-        all_planes = ops.planes_for_kernels(all_planes, n_rays * S)
-        flat_planes = [p for grp in all_planes for p in grp]
         beta = ops.beta_tensor(decoders.beta, rays_o.device)
         if ops.ext_render_ok(rays_o, self.n_stratified, _rand):
             # the common case as ONE compiled call (eslam_torch_ext.cpp); everything below is the same sequence through ctypes
-            return ops.ext_render(self._ext_cfg(truncation, decoders), rays_o, rays_d, gt_depth, beta, flat_planes,
-                                  ops.decoder_params(decoders), self.n_stratified, self.n_importance, ops.current_fused_loss())
+            return ops.ext_render(self._ext_cfg(truncation, decoders), rays_o, rays_d, gt_depth, beta,
+                                  [p for grp in all_planes for p in grp], ops.decoder_params(decoders), self.n_stratified,
+                                  self.n_importance, ops.current_fused_loss(), ops.wants_relayout(all_planes, n_rays * S))
+        # planes in the reference's NCHW layout: per-call channels-last scratch copies (gradients flow back through them)
+        all_planes = ops.planes_for_kernels(all_planes, n_rays * S)
+        flat_planes = [p for grp in all_planes for p in grp]
         # training calls get a direction-sorted ray order (better L2 locality forward, bundling for the scatter); it only
         # depends on the rays, so it runs on a side stream next to the samplers
         grad_on = torch.is_grad_enabled()

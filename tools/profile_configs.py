@@ -31,8 +31,11 @@ only = sys.argv[2].split(',') if len(sys.argv) > 2 else None
 rows = []
 for name, scene, R, ns, ni, zf in (("room0_4096x64", "room0", 4096, 56, 8, 0.0), ("scene0000_8192x96", "scene0000", 8192, 88, 8, 0.1),
                                    ("scene0000_1024x96", "scene0000", 1024, 88, 8, 0.1), ("freiburg_5000x56", "freiburg1_desk", 5000, 48, 8, 0.1),
-                                   ("room0_200x32", "room0", 200, 24, 8, 0.0)):
-    if only and name not in only: continue
+                                   ("room0_200x32", "room0", 200, 24, 8, 0.0),
+                                   # in-between sizes (only when named): where the scatter's bundle size switches
+                                   ("room0_2048x64", "room0", 2048, 56, 8, 0.0), ("room0_1024x64", "room0", 1024, 56, 8, 0.0),
+                                   ("room0_3072x64", "room0", 3072, 56, 8, 0.0)):
+    if (only and name not in only) or (not only and name in ("room0_2048x64", "room0_1024x64", "room0_3072x64")): continue
     wl = harness.make_workload(scene, R, ns, ni, device=dev, zero_frac=zf)
     for _ in range(5): wl.step()
     prof = kernel_profile(wl.step)
