@@ -232,6 +232,7 @@ class ShardedMapper:
         self.group = group
         self.weights = tuple(losses.MAPPING_W if weights is None else weights)
         self._collective = dist.is_available() and dist.is_initialized()     # (a lone process without a group: nothing to sum with)
+        self._agreed = 0                 # eager iterations whose list length has been compared across the ranks
         self.world = dist.get_world_size(group) if self._collective else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.window = source if isinstance(source, MappingWindow) else None
@@ -441,6 +442,15 @@ class ShardedMapper:
             n = self._marked()
             view = self._buf[:self._tail_pad + 32 * n]
             if self._collective:
+                if self._agreed < 2 and self.world > 1:
+                    # the list's length is a function of the whole batch's geometry, which every rank holds: ranks that disagree
+                    # (different seeds, different inputs) would all-reduce buffers of different lengths - say so instead
+                    self._agreed += 1
+                    lohi = torch.tensor([n, -n], dtype=torch.int64, device=view.device if dist.get_backend(self.group) == "nccl" else "cpu")
+                    dist.all_reduce(lohi, op=dist.ReduceOp.MAX, group=self.group)
+                    if int(lohi[0]) != n or int(-lohi[1]) != n:
+                        raise RuntimeError(f"ShardedMapper: this rank marked {n} texels, the ranks' counts span {int(-lohi[1])}..{int(lohi[0])}: "
+                                           "every rank must hold the same batch (same seed, same keyframe window)")
                 dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
             self.last_exchange = (view.numel() * 4, self.grads.flat.numel() * 4)
         else:
