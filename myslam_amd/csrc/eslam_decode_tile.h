@@ -257,6 +257,20 @@ __device__ __forceinline__ void store_features(float* feat_out, int64_t pt, int 
     }
 }
 
+// The same stores as buffer stores that are ALWAYS issued: `byte_off` = the row's byte offset + d * 256 + q * 16, or an offset
+// beyond the descriptor's range for a row that does not exist (the hardware drops the store).  A predicated global store sits
+// behind a branch, the compiler cannot count it, and every s_waitcnt for an OLDER load then waits for the stores as well (a
+// wave's loads and stores retire in order on one counter): with counted stores the wait names how many may stay in flight.
+typedef unsigned uint4_bits __attribute__((ext_vector_type(4)));
+#define ESLAM_OOB_OFFSET 0xFFFFFF00u
+template <bool NT = false>
+__device__ __forceinline__ void store_features_buffer(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, const float feat[16]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)          // piece j: level j >> 1, half j & 1 - the order of store_features
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_bits, (float4_t){feat[4 * j], feat[4 * j + 1], feat[4 * j + 2], feat[4 * j + 3]}),
+                                               rsrc, (int)byte_off + 64 * j, 0, NT ? 2 : 0);      // aux bit 1 = nt
+}
+
 // the same 16 values read back (backward pass), gather role
 __device__ __forceinline__ void load_features(const float* feat_in, int64_t pt, int d, int q, float feat[16]) {
     const float* src = feat_in + pt * 128 + d * 64 + 4 * q;

@@ -107,6 +107,12 @@ struct RayBwdIn {                  // MODE >= 1: what the composite backward of 
 // LOWP: the mixed-precision tile (eslam_decode_tile.h): hidden layers recomputed and every product of the backward pass on
 // bf16 MFMA (16x16x32 / 16x16x16) with float32 accumulation - 15 MFMAs of 16 cycles per 16 points and decoder instead of
 // 68 of 32 cycles; features, activations' masks, biases and all accumulators stay float32.
+#ifndef BWD_BUFSTORE
+#define BWD_BUFSTORE 1    // A/B switch: 0 = the feature-gradient rows leave through predicated global stores (round 2)
+#endif
+#ifndef BWD_TILE_AHEAD
+#define BWD_TILE_AHEAD 1  // A/B switch: 0 = a tile requests its own first block of rows (and waits for them) at its head
+#endif
 #ifndef BWD_ABLATE
 #define BWD_ABLATE 0      // profiling only (make variant VFLAGS=-DBWD_ABLATE=n): 1 no g_feat stores, 2 no weight gradients, 4 no feature loads
 #endif
@@ -175,34 +181,67 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
 #define STAMP(i)
 #endif
 
+    typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t gfrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g_feat, 0, (int)((unsigned)N * 512u), 0x00020000);
+    // four stores the hardware drops (offsets beyond the descriptor's range; distinct, so that none is eliminated): they put
+    // "exactly four stores are younger than every load issued before" into the compiler's picture where a loop is entered
+    auto dropped_stores = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b128((uint4_t){0u, 0u, 0u, 0u}, gfrsrc, (int)(0xFFFFFF00u + 16u * j), 0, 0);
+    };
+    // the block's feature-gradient rows, gather role: four 16-byte stores per lane (both tiles: piece j at byte 64 j of the
+    // decoder's half row), ALWAYS issued; N * 512 < 2^32 - 256 is checked at the launch
+    auto store_rows = [&](const int64_t p0, const int b, const int nvalid, const float gf[16]) {
+        if (BWD_ABLATE & 1) return;
+        const unsigned off = (16 * b + gp < nvalid) ? (unsigned)(p0 + 16 * b + gp) * 512u + (unsigned)(d * 256 + gq * 16) : 0xFFFFFF00u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4_t, (float4_t){gf[4 * j], gf[4 * j + 1], gf[4 * j + 2], gf[4 * j + 3]}),
+                                                   gfrsrc, (int)off + 64 * j, 0, 0);
+    };
     // MLP backward of one tile of <= 64 points starting at point p0; go[] = this decoder's pre-activation output
     // gradients of the lane's point (sample role)
-    auto tile_bwd = [&](const int64_t p0, const int nvalid, const float go[4]) {
+    auto load_block = [&](int b, float4_t v[4], const int64_t pbase) {
+        const int64_t pt = min(pbase + 16 * b + gp, N - 1);
+        if (LOWP) {      // bf16 features (store_features_lp): channels 8gq..8gq+7 of each level, 16 bytes per level
+            const short* fp = (const short*)feat + pt * 128 + d * 64 + 8 * gq;
+            v[0] = *(const float4_t*)(fp);
+            v[1] = *(const float4_t*)(fp + 32);
+            v[2] = v[3] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            return;
+        }
+        if (BWD_ABLATE & 4) { v[0] = v[1] = v[2] = v[3] = (float4_t){0.1f, 0.2f, -0.1f, 0.3f}; return; }
+        const float* fp = feat + pt * 128 + d * 64 + 4 * gq;     // piece gq = channels 4gq.., 16+4gq.. of a level
+        v[0] = *(const float4_t*)(fp);
+        v[1] = *(const float4_t*)(fp + 16);
+        v[2] = *(const float4_t*)(fp + 32);
+        v[3] = *(const float4_t*)(fp + 48);
+    };
+#define TOUCH(x) asm volatile("" :: "v"(x))
+#define TOUCH_ROWS { TOUCH(fnext[0]); TOUCH(fnext[1]); TOUCH(fnext[2]); TOUCH(fnext[3]); }
+    // fnext: the rows of the block that comes next - of this tile, or (BWD_TILE_AHEAD) block 0 of the tile at p0_next, requested
+    // by this tile's last block in front of its stores and waited for by the CALLER (TOUCH_ROWS) before it requests anything
+    constexpr bool AHEAD = BWD_BUFSTORE && BWD_TILE_AHEAD;
+    float4_t fnext[4];
+    auto tile_bwd = [&](const int64_t p0, const int nvalid, const float go[4], const int64_t p0_next) {
         const int nblk = (nvalid + 15) >> 4;
+        __builtin_assume(nblk >= 1);
 #pragma unroll
         for (int o = 0; o < 3; ++o) gb3[o] += go[o];
         *(float4_t*)(gt + lane * 4) = (float4_t){go[0], go[1], go[2], go[3]};
 
         // gather role: the 16 features of point 16b + gp, piece gq.  The rows of block b+1 are requested before block b is
         // computed: at 2 waves per SIMD nothing else hides the ~2k-cycle load latency.
-        auto load_block = [&](int b, float4_t v[4]) {
-            const int64_t pt = min(p0 + 16 * b + gp, N - 1);
-            if (LOWP) {      // bf16 features (store_features_lp): channels 8gq..8gq+7 of each level, 16 bytes per level
-                const short* fp = (const short*)feat + pt * 128 + d * 64 + 8 * gq;
-                v[0] = *(const float4_t*)(fp);
-                v[1] = *(const float4_t*)(fp + 32);
-                v[2] = v[3] = (float4_t){0.f, 0.f, 0.f, 0.f};
-                return;
-            }
-            if (BWD_ABLATE & 4) { v[0] = v[1] = v[2] = v[3] = (float4_t){0.1f, 0.2f, -0.1f, 0.3f}; return; }
-            const float* fp = feat + pt * 128 + d * 64 + 4 * gq;     // piece gq = channels 4gq.., 16+4gq.. of a level
-            v[0] = *(const float4_t*)(fp);
-            v[1] = *(const float4_t*)(fp + 16);
-            v[2] = *(const float4_t*)(fp + 32);
-            v[3] = *(const float4_t*)(fp + 48);
-        };
-        float4_t fnext[4];
-        load_block(0, fnext);
+        if (!AHEAD) load_block(0, fnext, p0);
+        // A wave's loads and stores retire in order on ONE counter (vmcnt).  A block's rows are requested a block ahead, i.e.
+        // BEFORE the previous block's four feature-gradient stores, so "all but the 4 youngest operations have retired" is all
+        // the top of a block has to wait for - but the compiler can only say so if it can COUNT the stores: as predicated
+        // global stores behind a branch (rows past the tile's end) it cannot, waits for vmcnt(0), and every block - and every
+        // ray's first use of its prefetched inputs - sat out the store acknowledgement of the block before (~2 k and ~5 k
+        // cycles: 45 % of a ray's ~30 k, profiles/r02/t_*).  The stores are therefore buffer stores that are ALWAYS issued - rows
+        // past the end get an offset beyond the descriptor's range, which the hardware drops - and four such dropped stores
+        // behind the first block's loads give the loop's entry the same shape as its back edge.
+        if (BWD_BUFSTORE && !AHEAD) dropped_stores();
 #pragma unroll 1
         for (int b = 0; b < nblk; ++b) {
             float ft[16];
@@ -210,7 +249,10 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
             for (int i = 0; i < 4; ++i) {
                 ft[i] = fnext[0][i]; ft[4 + i] = fnext[1][i]; ft[8 + i] = fnext[2][i]; ft[12 + i] = fnext[3][i];
             }
-            if (b + 1 < nblk) load_block(b + 1, fnext);       // (two blocks ahead: 250 VGPRs, no faster)
+            // (two blocks ahead: 250 VGPRs, no faster.)  ONE request site with a selected address: two sites behind an if / else
+            // made the compiler wait for vmcnt(0)
+            if (AHEAD) load_block(0, fnext, b + 1 < nblk ? p0 + 16 * (b + 1) : p0_next);
+            else if (b + 1 < nblk) load_block(b + 1, fnext, p0);
             // the same rows again in the "feature on the lane" layout of the g_W1 contraction (B operand): requested
             // here so that the L1/L2 latency is covered by the 28 MFMAs of the recompute instead of stalling them later
             // float32 path: NOT re-read from memory but handed over through a wave-private LDS tile, written here in the
@@ -276,7 +318,8 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
                     for (int i = 0; i < 4; ++i) gf[4 * mb + i] = acc[i];
                 }
                 to_gather_role<true, 16>(gf, lane);
-                if (p0 + 16 * b + gp < p0 + nvalid) {       // gather-role lane (point, g): features 16 mb + 4 g + i
+                if (BWD_BUFSTORE) store_rows(p0, b, nvalid, gf);
+                else if (p0 + 16 * b + gp < p0 + nvalid) {       // gather-role lane (point, g): features 16 mb + 4 g + i
                     float* dst = g_feat + (p0 + 16 * b + gp) * 128 + d * 64 + 4 * gq;
 #pragma unroll
                     for (int mb = 0; mb < 4; ++mb)
@@ -313,7 +356,8 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
             }
             STAMP(3)
             to_gather_role<true, 16>(gf, lane);
-            if (!(BWD_ABLATE & 1) && p0 + 16 * b + gp < p0 + nvalid) store_features(g_feat, p0 + 16 * b + gp, d, gq, gf);
+            if (BWD_BUFSTORE) store_rows(p0, b, nvalid, gf);
+            else if (!(BWD_ABLATE & 1) && p0 + 16 * b + gp < p0 + nvalid) store_features(g_feat, p0 + 16 * b + gp, d, gq, gf);
             }
             STAMP(4)
             if (!WGRAD || (BWD_ABLATE & 2)) continue;
@@ -375,7 +419,12 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
 
     if (MODE == 0) {
         const int64_t ntiles = (N + 63) / 64;
-        for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+        int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+        if (AHEAD && tile < ntiles) {
+            load_block(0, fnext, tile * 64);
+            dropped_stores();
+        }
+        for (; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
             const int64_t p0 = tile * 64;
             const int nvalid = (int)min((int64_t)64, N - p0);
             // sample role: pre-activation output gradients of this decoder
@@ -385,11 +434,13 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
                 if (d == 0) go[0] = g[3];
                 else { go[0] = g[0]; go[1] = g[1]; go[2] = g[2]; }
             }
-            tile_bwd(p0, nvalid, go);
+            if (AHEAD) TOUCH_ROWS
+            tile_bwd(p0, nvalid, go, (tile + (int64_t)gridDim.x * 4) * 64);
         }
     } else {
         const int R = rb.R, S = rb.S;
         const int nchunk = (S + WAVE - 1) / WAVE;
+        __builtin_assume(nchunk >= 1);             // (S >= 1 is checked at the launch; lets the compiler count a ray's stores)
         const float beta = rb.beta[0];
         LossW lw = {};
         LossK lk = {};
@@ -442,9 +493,28 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
         int ray = blockIdx.x * 4 + wave;
         RayIn rin = {};
         ChunkIn cin = {};
-        if (ray < R) { rin = load_ray(ray); cin = load_chunk(ray, nchunk - 1); }
+        if (ray < R) {
+            rin = load_ray(ray);
+            cin = load_chunk(ray, nchunk - 1);
+            if (AHEAD) load_block(0, fnext, (int64_t)ray * S + (nchunk - 1) * WAVE);
+        }
+        constexpr bool COUNTED = BWD_BUFSTORE != 0;           // the waits below are counted by the compiler: see tile_bwd
+        if (COUNTED) dropped_stores();
+#define TOUCH_CHUNK(ci) { TOUCH(ci.sd); TOUCH(ci.z); TOUCH(ci.cr); TOUCH(ci.cg); TOUCH(ci.cb); TOUCH(ci.gs); }
         for (; ray < R; ray += stride) {
             const int64_t base = (int64_t)ray * S;
+            // What is requested ahead - this ray's scalars and its last chunk a ray ago, a further chunk a tile ago - is waited
+            // for HERE, in front of the next requests and behind the four stores that ended the tile in between: vmcnt(4).
+            // (Waited for at its first use further down, the wait would cover the requests issued meanwhile as well - the
+            // compiler cannot count those: optional pointers, rows past S - and expose their whole latency in every ray:
+            // 5.5 k cycles of a ray's ~30 k, profiles/r02/t_*.)
+            if (COUNTED) {
+                TOUCH(rin.gd); TOUCH(rin.gr); TOUCH(rin.gg); TOUCH(rin.gb); TOUCH(rin.gtd); TOUCH(rin.dep); TOUCH(rin.cr); TOUCH(rin.cg);
+                TOUCH(rin.cb); TOUCH(rin.tr); TOUCH(rin.tg); TOUCH(rin.tb); TOUCH(rin.mask);
+                TOUCH_CHUNK(cin)
+                if (AHEAD) TOUCH_ROWS
+            }
+            ChunkIn ch = cin;
             RayIn rnx = {};
             ChunkIn cnx = {};
             if (ray + stride < R) { rnx = load_ray(ray + stride); cnx = load_chunk(ray + stride, nchunk - 1); }
@@ -471,11 +541,16 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
             }
             // pass B: chunks in reverse, carrying the suffix sum of gw*w
             float carry = 0.0f;
-            for (int c = nchunk - 1; c >= 0; --c) {
+            int c = nchunk - 1;
+            do {
+                // S > 64: the chunk in front of this one is requested a tile ahead as well, and taken over behind the tile's stores.
+                // (No value still in flight is carried around a loop: the compiler copies loop-carried registers at the loop's
+                // entry, and a copy of a register that is still being loaded is a wait for everything requested so far.)
+                ChunkIn cn = {};
+                if (c > 0) cn = load_chunk(ray, c - 1);
                 float trans_in = 1.0f;
                 for (int k = 0; k < c; ++k) trans_in *= __shfl(myprod, k, WAVE);
                 const bool valid = c * WAVE + lane < S;
-                const ChunkIn ch = (c == nchunk - 1) ? cin : load_chunk(ray, c);
                 float gs = ch.gs;
                 if (MODE == 2 && valid) gs += loss_g_sdf(m, ch.z, ch.sd, gtd, li.tr, lk);
                 STAMP(7)
@@ -485,11 +560,19 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
                 if (d == 0) go[0] = o[3];
                 else { go[0] = o[0]; go[1] = o[1]; go[2] = o[2]; }
                 STAMP(0)
-                tile_bwd(base + c * WAVE, min(WAVE, S - c * WAVE), go);
-            }
+                // the tile after this one: the chunk in front of it, or the last chunk of the wave's next ray (rows past N are clamped)
+                tile_bwd(base + c * WAVE, min(WAVE, S - c * WAVE), go,
+                         c > 0 ? base + (c - 1) * WAVE : (int64_t)(ray + stride) * S + (nchunk - 1) * WAVE);
+                if (c > 0) {
+                    if (COUNTED) TOUCH_CHUNK(cn)
+                    if (AHEAD) TOUCH_ROWS
+                    ch = cn;
+                }
+            } while (--c >= 0);
             rin = rnx;
             cin = cnx;
         }
+#undef TOUCH_CHUNK
         // g_beta: one partial sum per workgroup of the sdf decoder (summed by dec_grad_reduce_kernel / beta_sum_kernel);
         // one atomic per ray on the single address of g_beta would serialise at the memory side (4096 of them: 50 us)
         __shared__ float beta_part[4];
@@ -747,6 +830,11 @@ static int bwd_common(const eslam_plane_t* planes, const eslam_decoders_t* dec, 
     float* beta_parts = slabs + (int64_t)MLP_BWD_MAX_WG * 4 * 2 * SLAB;
     rb.beta_parts = render ? beta_parts : nullptr;
     const LossGradIn none = {};
+    if (N * 512 >= ((int64_t)1 << 32) - 256) {     // the feature-gradient rows are addressed with 32-bit byte offsets (as in the scatter)
+        eslam_set_error("backward: %lld points exceed the 32-bit offset range of the feature-gradient buffer (8.3 M): split the batch",
+                        (long long)N);
+        return 1;
+    }
     eslam_prof_begin(PROF_MLP_BWD, st);
 #define LAUNCH_MB(MD, WG, LP) \
     hipLaunchKernelGGL((mlp_bwd_kernel<MD, WG, LP>), dim3(nwg, 2), dim3(256), 0, st, *dec, feat, g_o, N, g_feat, slabs, rb, \

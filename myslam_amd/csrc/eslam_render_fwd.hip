@@ -33,6 +33,12 @@ template <bool CL, bool SAVE, bool LOSS, bool LOWP>
 #ifndef FWD_CHAIN
 #define FWD_CHAIN 1
 #endif
+#ifndef FWD_Z_PERMUTE
+#define FWD_Z_PERMUTE 1        // a block's z values by lane permute from one load per chunk (0: one dependent load per block)
+#endif
+#ifndef FWD_BUFSTORE
+#define FWD_BUFSTORE 1         // the saved features leave through always-issued buffer stores (countable: store_features_buffer)
+#endif
 #ifndef FWD_WAVES
 #define FWD_WAVES 2            // waves per SIMD the gather kernels are compiled for: with one plane of loads in flight
                                // ahead of the FMAs the forward kernel needs 195 VGPRs; 2 waves/SIMD measured fastest
@@ -58,6 +64,8 @@ __global__ __launch_bounds__(256, FWD_WAVES) void render_fwd_kernel(const PlaneS
     const int wave = threadIdx.x >> 6;
     const int r = lane & 15, q = lane >> 4;                                  // MFMA role
     const int gp = gather_point<CL>(lane), gq = gather_piece<CL>(lane);     // gather role
+    // (R * S * 512 < 2^32 - 256 is checked at the launch when features are saved)
+    const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc((void*)feat_out, 0, (int)((unsigned)R * (unsigned)S * 512u), 0x00020000);
     float lv[A_COUNT];                     // LOSS: this lane's share of the accumulators
 #pragma unroll
     for (int k = 0; k < A_COUNT; ++k) lv[k] = 0.0f;
@@ -92,8 +100,11 @@ __global__ __launch_bounds__(256, FWD_WAVES) void render_fwd_kernel(const PlaneS
 
         float4_t out[2];
         // gather role: normalised coordinates of point 16b + gp of the chunk
+        // the chunk's z values, sample role (lane l: sample min(c0 + l, S - 1)); a block's points fetch theirs with a lane
+        // permute - as a load per block the value sat on the critical path of the NEXT block's first texel request
+        const float zs = zrow[min(c0 + lane, S - 1)];
         auto block_point = [&](int b, float& px, float& py, float& pz) {
-            const float zb = zrow[min(c0 + 16 * b + gp, S - 1)];
+            const float zb = FWD_Z_PERMUTE ? __shfl(zs, 16 * b + gp, WAVE) : zrow[min(c0 + 16 * b + gp, S - 1)];
             px = norm_coord(ox + dx * zb, bnd.lo[0], bnd.hi[0]);
             py = norm_coord(oy + dy * zb, bnd.lo[1], bnd.hi[1]);
             pz = norm_coord(oz + dz * zb, bnd.lo[2], bnd.hi[2]);
@@ -120,7 +131,12 @@ __global__ __launch_bounds__(256, FWD_WAVES) void render_fwd_kernel(const PlaneS
                     gather_features_chain(planes, d, cx, cy, cz, gq, feat, oz0, carry, last ? 1 : d, nx, ny, nz);
                     cx = nx; cy = ny; cz = nz;
                     if (SAVE) {
-                        if (sb < S) store_features<FWD_FEAT_NT != 0>(feat_out, (int64_t)ray * S + sb, d, gq, feat);
+                        if (FWD_BUFSTORE) {
+                            __builtin_amdgcn_sched_barrier(0);      // (left alone, the scheduler sinks the stores behind the MLP)
+                            store_features_buffer<FWD_FEAT_NT != 0>(frsrc, sb < S ? (unsigned)(ray * S + sb) * 512u + (unsigned)(d * 256 + gq * 16)
+                                                                                  : ESLAM_OOB_OFFSET, feat);
+                            __builtin_amdgcn_sched_barrier(0);
+                        } else if (sb < S) store_features<FWD_FEAT_NT != 0>(feat_out, (int64_t)ray * S + sb, d, gq, feat);
                     }
                     to_mfma_role<CL, 16>(feat, lane);
                     DecFrag f;
@@ -163,7 +179,7 @@ __global__ __launch_bounds__(256, FWD_WAVES) void render_fwd_kernel(const PlaneS
         // ---- sample role: activations, alpha, transmittance scan, composite (Renderer.py:140-153) ----
         const bool valid = lane < nvalid;
         const int s = c0 + lane;
-        const float z = valid ? zrow[s] : 0.0f;
+        const float z = valid ? (FWD_Z_PERMUTE ? zs : zrow[s]) : 0.0f;
         const float sdf = tanhf(out[0][0]);
         const float cr = sigmoidf_(out[1][0]), cg = sigmoidf_(out[1][1]), cb = sigmoidf_(out[1][2]);
         if (valid) {
@@ -331,6 +347,11 @@ static int render_fwd_common(const char* who, const eslam_plane_t* planes, const
     const Bound bnd = make_bound(bound6_host);
     const bool cl = eslam_planes_channels_last(planes, 0, NPL);
     const bool save = feat != nullptr;
+    if (save && (int64_t)R * S * 512 >= ((int64_t)1 << 32) - 256) {       // saved features are addressed with 32-bit byte offsets
+        eslam_set_error("%s: %lld points exceed the 32-bit offset range of the saved-feature buffer (8.3 M): split the batch", who,
+                        (long long)R * S);
+        return 1;
+    }
     const int nblocks = (R + 3) / 4;
     static const int resident = [] {        // workgroups the chip holds at once: FWD_WAVES waves per SIMD = FWD_WAVES workgroups per CU
         int dev = 0, cus = 256;

@@ -42,6 +42,11 @@ cp $OUT/r03_traffic.json profiles/r03_traffic.json
 python3 bench.py > $OUT/bench_4096x64.json 2> $OUT/bench.err
 python3 bench.py --strong --steps 50 --warmup 10 > $OUT/bench_strong_n1.json 2> $OUT/bench_strong.err
 python3 bench.py --lowp --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_lowp_5000x56.json 2> $OUT/bench_lowp.err
+# host time of the eager step: Python glue / compiled glue, channels-last / NCHW planes
+ESLAM_TORCH_EXT=0 python3 tools/host_profile.py > $OUT/host_profile_python_glue.txt 2>/dev/null
+python3 tools/host_profile.py > $OUT/host_profile_compiled_glue.txt 2>/dev/null
+ESLAM_TORCH_EXT=0 python3 tools/host_profile.py nchw > $OUT/host_profile_python_glue_nchw.txt 2>/dev/null
+python3 tools/host_profile.py nchw > $OUT/host_profile_compiled_glue_nchw.txt 2>/dev/null
 # keep the merge small: drop the raw per-dispatch traces, keep summaries
 find $OUT -name '*kernel_trace.csv' -delete; find $OUT -name '*counter_collection.csv' -size +4M -delete; find $OUT -name '*.db' -delete
 tail -c 1200 $OUT/bench_4096x64.json; echo; head -c 1500 $OUT/r03_traffic.json
