@@ -489,13 +489,25 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
             }
             return x;
         };
+        // S > 64: the sdf values of the chunks in front of the last one (pass A below), requested a ray ahead like the rest
+        static_assert(ESLAM_MAX_SAMPLES <= 4 * WAVE, "pass A prefetch holds three chunks");
+        struct PassA { float sd[3]; };
+        auto load_pa = [&](int ray) {
+            PassA x = {{0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (k < nchunk - 1) x.sd[k] = rb.sdf[(int64_t)ray * S + k * WAVE + lane];      // chunks before the last are full
+            return x;
+        };
         const int stride = gridDim.x * 4;
         int ray = blockIdx.x * 4 + wave;
         RayIn rin = {};
         ChunkIn cin = {};
+        PassA pin = {{0.f, 0.f, 0.f}};
         if (ray < R) {
             rin = load_ray(ray);
             cin = load_chunk(ray, nchunk - 1);
+            pin = load_pa(ray);
             if (AHEAD) load_block(0, fnext, (int64_t)ray * S + (nchunk - 1) * WAVE);
         }
         constexpr bool COUNTED = BWD_BUFSTORE != 0;           // the waits below are counted by the compiler: see tile_bwd
@@ -512,12 +524,14 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
                 TOUCH(rin.gd); TOUCH(rin.gr); TOUCH(rin.gg); TOUCH(rin.gb); TOUCH(rin.gtd); TOUCH(rin.dep); TOUCH(rin.cr); TOUCH(rin.cg);
                 TOUCH(rin.cb); TOUCH(rin.tr); TOUCH(rin.tg); TOUCH(rin.tb); TOUCH(rin.mask);
                 TOUCH_CHUNK(cin)
+                TOUCH(pin.sd[0]); TOUCH(pin.sd[1]); TOUCH(pin.sd[2]);
                 if (AHEAD) TOUCH_ROWS
             }
             ChunkIn ch = cin;
             RayIn rnx = {};
             ChunkIn cnx = {};
-            if (ray + stride < R) { rnx = load_ray(ray + stride); cnx = load_chunk(ray + stride, nchunk - 1); }
+            PassA pnx = {{0.f, 0.f, 0.f}};
+            if (ray + stride < R) { rnx = load_ray(ray + stride); cnx = load_chunk(ray + stride, nchunk - 1); pnx = load_pa(ray + stride); }
             RayUp up;
             up.gd = rin.gd; up.gr = rin.gr; up.gg = rin.gg; up.gb = rin.gb;
             const float gtd = rin.gtd;
@@ -532,12 +546,14 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
             }
             // pass A: transmittance product of every chunk; lane c keeps chunk c's
             float myprod = 1.0f;
-            for (int c = 0; c < nchunk - 1; ++c) {           // (the last chunk's product is never needed)
-                const int s = c * WAVE + lane;               // chunks before the last are full
-                const float sd = rb.sdf[base + s];
-                const float alpha = 1.0f - expf(-beta * sigmoidf_(-sd * beta));
-                const float cp = wave_lane<63>(wave_incl_prod((1.0f - alpha) + 1e-10f, lane));
-                if (lane == c) myprod = cp;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {                    // (the last chunk's product is never needed)
+                if (c < nchunk - 1) {
+                    const float sd = pin.sd[c];
+                    const float alpha = 1.0f - expf(-beta * sigmoidf_(-sd * beta));
+                    const float cp = wave_lane<63>(wave_incl_prod((1.0f - alpha) + 1e-10f, lane));
+                    if (lane == c) myprod = cp;
+                }
             }
             // pass B: chunks in reverse, carrying the suffix sum of gw*w
             float carry = 0.0f;
@@ -571,6 +587,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_kernel(const eslam_decoders_t 
             } while (--c >= 0);
             rin = rnx;
             cin = cnx;
+            pin = pnx;
         }
 #undef TOUCH_CHUNK
         // g_beta: one partial sum per workgroup of the sdf decoder (summed by dec_grad_reduce_kernel / beta_sum_kernel);
