@@ -31,8 +31,11 @@ __device__ __forceinline__ void axis(float u, int n, int& i0, int& i1, float& t)
 }
 
 // pts [N,3] normalised coordinates; out [N,128] features (d*64 + lvl*32 + channel)
+#ifndef UB_WAVES
+#define UB_WAVES 2                 // waves per SIMD the plain gather kernels are compiled for (-DUB_WAVES=3 / 4: occupancy study)
+#endif
 template <int MAP, int PIPE>
-__global__ __launch_bounds__(256, 2) void gather_kernel(const Planes planes, const float* __restrict__ pts, int N,
+__global__ __launch_bounds__(256, UB_WAVES) void gather_kernel(const Planes planes, const float* __restrict__ pts, int N,
                                                         float* __restrict__ out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tile = blockIdx.x * 4 + wave;           // 64 points per wave
