@@ -131,7 +131,9 @@ int eslam_sample_z_all_rng(const eslam_plane_t* planes, const eslam_decoders_t* 
  * src/common.py:204-218:  pts = o + d z -> normalise -> tri-plane bilinear gather (border, align_corners) ->
  * SDF / colour MLPs -> sdf2alpha -> transmittance scan -> composite.
  * Outputs: depth [R], rgb [R,3], sdf [R,S].  For a later backward pass also raw_rgb [R,S,3] (sigmoid outputs)
- * and feat [R*S,128] (geometry 64 || colour 64 features per sample); both may be NULL for inference.
+ * and feat [R*S,128] (geometry 64 || colour 64 features per sample); both may be NULL for inference.  With feat given,
+ * R*S is limited to 8 388 607 points (rows of feat, and of the backward pass's feature-gradient buffer, are addressed with
+ * 32-bit byte offsets: R*S*512 < 2^32 - 256); larger batches return an error - split them (inference has no such limit).
  * ray_order [R] (optional, from eslam_ray_order): the kernel walks the rays in that order with an XCD-contiguous
  * block mapping; outputs stay in the caller's ray order.  NULL = rays are processed as given, which measured FASTER
  * on MI355X (119 vs 123-125 us at 4096 x 64: neighbouring rays in flight together hit the same L2 channels), so the
