@@ -404,7 +404,10 @@ def run():
         # collective-free halves of the sharded step are captured separately and the one all-reduce stays eager.
         try:
             if mapper is not None:
-                mapper.capture()
+                # ONE graph per step - [unpack of the previous iteration's all-reduced gradients, this iteration's sampler, forward,
+                # backward, pack] - and the one all-reduce behind it (ShardedMapper.capture); flush() below drains the last iteration
+                # INSIDE the timed region, so K timed steps hold K fronts and K + 1 backs
+                mapper.capture(pipeline=True)
             else:
                 step = harness.GraphedStep(eager_step, wl.params())
             graphed = True
@@ -424,6 +427,8 @@ def run():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if mapper is not None and graphed:
+        mapper.flush()
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -466,7 +471,7 @@ def run():
                                "the backward kernel (eslam_render_bwd_loss)" +
                                ("; global set sizes computed redundantly on every rank from the whole batch (eslam_loss_set_sizes)"
                                 if mapper is not None else ""),
-                       "launch": ("hipGraph replay of the captured iteration" + (" (2 graphs, the one all-reduce eager between them)" if mapper is not None
+                       "launch": ("hipGraph replay of the captured iteration" + (" (one graph per step: [unpack of the previous iteration, this iteration up to its pack], the one all-reduce eager behind it)" if mapper is not None
                                                                                               else ""))
                        if graphed else "eager launches from Python"},
             # (ray-sharded runs: this rank's kernels on this rank's shard; the PMC bytes are collected for the N = 1 workload only)
