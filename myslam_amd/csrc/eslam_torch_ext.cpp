@@ -163,7 +163,7 @@ public:
         if (needs) {
             raw_rgb = at::empty({R, S, 3}, opt);
             feat = at::empty({R * S, 128}, opt);
-            perm = at::empty({R}, opt.dtype(at::kInt));
+            perm = at::empty({planes_grad ? R : 0}, opt.dtype(at::kInt));     // the scatter's bundling order: only planes with a gradient need it
         }
         if (io.relayout && R > 0) {
             auto cl = alloc_plane_grads(planes, Layout::channels_last);
@@ -179,15 +179,13 @@ public:
         std::vector<Tensor> grad_views;
         Tensor grad_flat;
         hipStream_t side = nullptr;
-        if (needs && R > 0) {
+        if (planes_grad && R > 0) {       // (tracking - planes without a gradient - has nothing for the side stream to do)
             side = side_stream(dev);
-            if (planes_grad) {
-                auto gv = alloc_plane_grads(planes);
-                grad_flat = gv.first;
-                grad_views = std::move(gv.second);
-            }
+            auto gv = alloc_plane_grads(planes);
+            grad_flat = gv.first;
+            grad_views = std::move(gv.second);
             check(eslam_stream_wait(side, st), "eslam_stream_wait");
-            if (planes_grad) check(eslam_zero_async(grad_flat.data_ptr<float>(), grad_flat.numel() * 4, side), "eslam_zero_async");
+            check(eslam_zero_async(grad_flat.data_ptr<float>(), grad_flat.numel() * 4, side), "eslam_zero_async");
             check(eslam_ray_order(rays_o.data_ptr<float>(), rays_d.data_ptr<float>(), (int)R, perm.data_ptr<int32_t>(), side), "eslam_ray_order");
         }
         if (R > 0) {
@@ -307,14 +305,14 @@ public:
                                         grgb.defined() ? grgb.data_ptr<float>() : nullptr, gsdf.defined() ? gsdf.data_ptr<float>() : nullptr,
                                         need_dec ? g_dec.data_ptr<float>() : nullptr, need_beta ? g_beta.data_ptr<float>() : nullptr,
                                         need_rays ? g_ro.data_ptr<float>() : nullptr, need_rays ? g_rd.data_ptr<float>() : nullptr,
-                                        perm.data_ptr<int32_t>(), ws.data_ptr(), st), "eslam_render_bwd_loss");
+                                        perm.numel() ? perm.data_ptr<int32_t>() : nullptr, ws.data_ptr(), st), "eslam_render_bwd_loss");
         } else {
             check(eslam_render_bwd(pd, &dd, bound, rays_o.data_ptr<float>(), rays_d.data_ptr<float>(), z.data_ptr<float>(), (int)R, (int)S,
                                    sdf.data_ptr<float>(), raw_rgb.data_ptr<float>(), feat.data_ptr<float>(), gdep.defined() ? gdep.data_ptr<float>() : nullptr,
                                    grgb.defined() ? grgb.data_ptr<float>() : nullptr, gsdf.defined() ? gsdf.data_ptr<float>() : nullptr,
                                    need_dec ? g_dec.data_ptr<float>() : nullptr, need_beta ? g_beta.data_ptr<float>() : nullptr,
                                    need_rays ? g_ro.data_ptr<float>() : nullptr, need_rays ? g_rd.data_ptr<float>() : nullptr,
-                                   perm.data_ptr<int32_t>(), ws.data_ptr(), st), "eslam_render_bwd");
+                                   perm.numel() ? perm.data_ptr<int32_t>() : nullptr, ws.data_ptr(), st), "eslam_render_bwd");
         }
         variable_list out(28);             // 27 tensor inputs + the IO argument's (undefined) slot
         if (need_ro) out[0] = g_ro;

@@ -47,7 +47,8 @@ class Renderer(object):
         wants_grad = planes_grad or (grad_on and (rays_o.requires_grad or rays_d.requires_grad or
                                                   any(p.requires_grad for p in ops.decoder_params(decoders)) or
                                                   (torch.is_tensor(decoders.beta) and decoders.beta.requires_grad)))
-        order = ops.ray_order_async(rays_o, rays_d, flat_planes if planes_grad else None) if wants_grad else None
+        # (the order bundles rays for the plane-gradient scatter; a call whose planes take no gradient - tracking - has no use for it)
+        order = ops.ray_order_async(rays_o, rays_d, flat_planes) if planes_grad else None
         z_vals = ops.sample_z(rays_o, rays_d, gt_depth, all_planes, decoders, self._bound6, truncation,
                               self.n_stratified, self.n_importance, self.perturb, _rand)
         # pts are normalised with decoders.bound (decoders.py:138), the importance sampler uses renderer.bound
