@@ -21,14 +21,16 @@ _SEPARATE_LOSS = os.environ.get("ESLAM_SEPARATE_LOSS", "0") == "1"
 
 class Workload:
     def __init__(self, scene_name, R, n_strat, n_imp, device, zero_frac=0.0, seed=0, channels_last=True,
-                 rays_grad=False, planes="normal", model_seed=0, shard=None, state="initial"):
+                 rays_grad=False, planes="normal", model_seed=0, shard=None, state="initial", cams=1):
         """seed: image / pixel choice of this rank's rays; model_seed: planes and decoders (same on every rank of a
         data-parallel job, whose replicas must be identical).  shard = (rank, world): build the WHOLE batch (give every
         rank the same seed) and keep this rank's contiguous slice of its rays (parallel.shard_slice) - the ray-sharded
         mapping iteration of SURVEY.md section 8(e); R_total is the batch's ray count.
         state: "initial" = the reference's initial state (planes ~ 0.01, sdf ~ 0: the FIRST sample of a ray takes 99.9 % of
         the compositing weight); "trained" = planes x 60 and the SDF head's bias + 0.55, which spreads the weights over ~20
-        samples per ray - the state parity tests need to see the colour features of later samples at all."""
+        samples per ray - the state parity tests need to see the colour features of later samples at all.
+        cams > 1: the batch of a keyframe WINDOW (src/Mapper.py:308-319): R // cams pixels from each of `cams` cameras standing
+        on a ring round the AABB centre and looking outwards in different directions (the bench workload is ONE camera)."""
         dev = torch.device(device)
         self.device = dev
         sc = scn.make_scene(scene_name)
@@ -59,12 +61,22 @@ class Workload:
         eslam = SimpleNamespace(bound=sc.bound, device=dev, H=sc.H, W=sc.W, fx=sc.fx, fy=sc.fy, cx=sc.cx, cy=sc.cy)
         self.renderer = Renderer(cfg, eslam)
         self.c2w = scn.center_pose(sc)
-        depth_img = torch.from_numpy(synth.depth_image(sc.H, sc.W, 10 + seed, zero_frac)).to(dev)[None]
-        color_img = torch.from_numpy(synth.color_image(sc.H, sc.W, 12 + seed)).to(dev)[None]
+        cams = int(cams)
+        depth_img = torch.from_numpy(synth.depth_image(sc.H, sc.W, 10 + seed, zero_frac)).to(dev)[None].repeat(cams, 1, 1)
+        color_img = torch.from_numpy(synth.color_image(sc.H, sc.W, 12 + seed)).to(dev)[None].repeat(cams, 1, 1, 1)
+        R = (R // cams) * cams
         idx = torch.from_numpy(synth.hash_randint(sc.H * sc.W, (R,), 50_000 + seed)).to(dev)
-        c2ws = self.c2w[None].to(dev)
+        c2ws = self.c2w[None].repeat(cams, 1, 1)
+        if cams > 1:
+            import math
+            half = 0.15 * (sc.bound[:, 1] - sc.bound[:, 0])
+            for k in range(cams):
+                a = 2.0 * math.pi * k / cams
+                c2ws[k, :3, :3] = torch.tensor([[math.cos(a), 0.0, math.sin(a)], [0.0, 1.0, 0.0], [-math.sin(a), 0.0, math.cos(a)]])
+                c2ws[k, :3, 3] += torch.tensor([math.sin(a), 0.0, math.cos(a)]) * half
+        c2ws = c2ws.to(dev)
         with torch.no_grad():
-            ro, rd, gd, gc = get_samples_at(idx, 0, sc.H, 0, sc.W, R, sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, c2ws,
+            ro, rd, gd, gc = get_samples_at(idx, 0, sc.H, 0, sc.W, R // cams, sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, c2ws,
                                             depth_img, color_img)
             inside = ops.aabb_exit(ro, rd, ops.bound_to_host(sc.bound)) >= gd           # Mapper.py:322-332
         ro, rd, gd, gc = ro[inside], rd[inside], gd[inside], gc[inside]

@@ -1,5 +1,6 @@
 """Eager steps of one BASELINE.json workload for the rocprofv3 passes (kernel trace, PMC) and the ESLAM_SC_* scatter switches:
-    python tools/dbg_scatter.py [scene rays n_strat n_imp zero_frac [lowp]]        (default: the bench workload, room0 4096 x 64)
+    python tools/dbg_scatter.py [scene rays n_strat n_imp zero_frac [lowp | camsN]]        (default: the bench workload, room0 4096 x 64;
+    camsN: the batch of an N-camera keyframe window instead of one camera's rays)
 Also launches one calibration read of known size (a float32 sum over 256 MiB) so that collect_traffic.py can turn the L2
 request counters of the same pass into bytes."""
 import ctypes, os, sys, time, torch
@@ -8,8 +9,10 @@ from myslam_amd import harness, _hip
 dev = torch.device('cuda:0')
 a = sys.argv[1:]
 lowp = len(a) > 5 and a[5] == 'lowp'
+cams = int(a[5][4:]) if len(a) > 5 and a[5].startswith('cams') else 1
 wl = harness.make_workload(a[0] if a else 'room0', int(a[1]) if a else 4096, int(a[2]) if a else 56, int(a[3]) if a else 8,
-                           device=dev, zero_frac=float(a[4]) if len(a) > 4 else 0.0)
+                           device=dev, zero_frac=float(a[4]) if len(a) > 4 else 0.0, cams=cams)
+if cams > 1: print(f"{cams} cameras, {wl.R} rays kept of the batch")
 step = wl.step
 if lowp:
     from myslam_amd import lowp as lp, ops
