@@ -28,12 +28,13 @@
 extern "C" {
 #endif
 
-#define ESLAM_ABI_VERSION 4
+#define ESLAM_ABI_VERSION 5
 #define ESLAM_C_DIM 32          /* feature channels per plane (configs/ESLAM.yaml:77)               */
 #define ESLAM_HIDDEN 16         /* decoder hidden width (src/networks/decoders.py:39)               */
 #define ESLAM_FEAT (2 * ESLAM_C_DIM)   /* coarse || fine                                          */
 #define ESLAM_N_PLANES 12
 #define ESLAM_MAX_SAMPLES 256   /* samples per ray supported by the per-ray kernels                  */
+#define ESLAM_RAY_ORDERS 3      /* eslam_ray_order writes one order per plane orientation (xy, xz, yz)    */
 /* floats in the flat decoder-gradient vector, in the order of eslam_decoders_t (beta excluded)      */
 #define ESLAM_N_DEC_PARAMS (2 * (16 * 64 + 16 + 16 * 16 + 16) + (1 * 16 + 1) + (3 * 16 + 3))
 
@@ -134,7 +135,7 @@ int eslam_sample_z_all_rng(const eslam_plane_t* planes, const eslam_decoders_t* 
  * and feat [R*S,128] (geometry 64 || colour 64 features per sample); both may be NULL for inference.  With feat given,
  * R*S is limited to 8 388 607 points (rows of feat, and of the backward pass's feature-gradient buffer, are addressed with
  * 32-bit byte offsets: R*S*512 < 2^32 - 256); larger batches return an error - split them (inference has no such limit).
- * ray_order [R] (optional, from eslam_ray_order): the kernel walks the rays in that order with an XCD-contiguous
+ * ray_order [ESLAM_RAY_ORDERS][R] (optional, from eslam_ray_order; the forward uses the first): the kernel walks the rays in that order with an XCD-contiguous
  * block mapping; outputs stay in the caller's ray order.  NULL = rays are processed as given, which measured FASTER
  * on MI355X (119 vs 123-125 us at 4096 x 64: neighbouring rays in flight together hit the same L2 channels), so the
  * shipped binding passes NULL here and hands the order to eslam_render_bwd only, whose scatter needs it.
@@ -178,9 +179,12 @@ int eslam_render_fwd_lowp(const eslam_plane_t* planes_f16, const eslam_decoders_
                           const float* rays_o, const float* rays_d, const float* z_vals, int R, int S, float* depth,
                           float* rgb, float* sdf, eslam_stream_t stream);
 
-/* Ray order for eslam_render_fwd / eslam_render_bwd: perm [R] <- ray ids sorted by a 15-bit Morton key of the point one
- * metre along each ray (single-pass counting sort, chunks of 8192 rays).  Depends only on the rays, so a caller can
- * run it on a side stream next to the samplers.                                                              */
+/* Ray orders for eslam_render_bwd's plane-gradient scatter (and, optionally, eslam_render_fwd): perm [ESLAM_RAY_ORDERS][R]
+ * <- three permutations of the ray ids, one per plane orientation (xy, xz, yz).  Rays that share one origin (one camera's
+ * batch) are sorted, for orientation o, by the azimuth of their direction projected into that plane - the rays of a bundle
+ * then cover a thin wedge of the plane and share its cells; batches with several origins get the same order three times
+ * (a Morton key of the point one metre along each ray).  Single-pass counting sorts, chunks of 8192 rays.  Depends only on the
+ * rays, so a caller can run it on a side stream next to the samplers.  (ABI 5: perm was [R].)                           */
 int eslam_ray_order(const float* rays_o, const float* rays_d, int R, int32_t* perm, eslam_stream_t stream);
 
 /* Bytes of scratch eslam_render_bwd / eslam_decode_bwd need for n_points = R*S points.               */

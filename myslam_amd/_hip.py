@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ESLAM_HIP_LIB: another build of the SAME library (A/B of compile-time kernel variants: `make variant`, tools/ab_inproc.py); never a fallback
 LIB_PATH = os.environ.get("ESLAM_HIP_LIB") or os.path.join(_HERE, "lib", "libeslam_hip.so")
 
-ABI_VERSION = 4              # ESLAM_ABI_VERSION
+ABI_VERSION = 5              # ESLAM_ABI_VERSION
+RAY_ORDERS = 3               # ESLAM_RAY_ORDERS: eslam_ray_order writes one order per plane orientation
 N_DEC_PARAMS = 2692
 N_PLANES = 12
 

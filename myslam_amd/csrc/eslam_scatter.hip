@@ -51,6 +51,9 @@ __device__ __forceinline__ unsigned spread3(unsigned v) {      // 10 bits -> eve
 // determine: the key is then the 16-bit Hilbert index of the direction's gnomonic projection about the mean
 // direction - neighbours along the curve are always neighbours in the image.  Measured on the bench workload:
 // 14 % fewer cell flushes, scatter 124 -> 116 us (tools/sim_order.py, tools/exp_order.py).
+#ifndef RAY_ORDER_AZIMUTH
+#define RAY_ORDER_AZIMUTH 1       // A/B switch: 0 = the three orders are the same 2-D Hilbert order (round 2)
+#endif
 #define ORD_BITS 5
 #define ORD_CELLS (1 << (3 * ORD_BITS))      // 32768 words = 65536 packed 16-bit counters = 128 KB of LDS
 #define ORD_PER_THREAD (SORT_MAX / 1024)
@@ -69,6 +72,14 @@ __global__ __launch_bounds__(1024) void ray_order_kernel(const float* __restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int base = blockIdx.x * SORT_MAX;
     const int n = min(SORT_MAX, R - base);
+    // blockIdx.y = plane orientation (0: xy, 1: xz, 2: yz): order number o is written to perm + o * R.  When the rays share one
+    // origin, order o sorts them by the AZIMUTH of their direction projected into plane o: the rays of a bundle then lie on top
+    // of each other in that plane's projection whatever their angle out of it, and that is what shares cells - a plane collapses
+    // one axis, so a square patch of the image (the Hilbert order: one order for all planes) spreads over many more cells of
+    // each plane than a thin wedge does.  tools/sim_order.py, bench rays: 58.8 k cell flushes against 135 k.
+    const int orient = blockIdx.y;
+    perm += (size_t)orient * R;
+    const int pa = orient == 2 ? 1 : 0, pb = orient == 0 ? 1 : 2;       // the plane's two axes
 
     // Rays are re-read from memory (98 KB, cache resident) in every pass instead of being held in 24 registers per
     // thread: at 1024 threads per workgroup the budget is 128 VGPRs, and the Hilbert path spilled.
@@ -133,9 +144,17 @@ __global__ __launch_bounds__(1024) void ray_order_kernel(const float* __restrict
         const float el = rsqrtf(e10 * e10 + e11 * e11 + e12 * e12);
         e10 *= el; e11 *= el; e12 *= el;
         const float e20 = m1 * e12 - m2 * e11, e21 = m2 * e10 - m0 * e12, e22 = m0 * e11 - m1 * e10;
-        auto chart = [&](int ray, float& u, float& v) {  // gnomonic chart about the mean direction, clamped at ~87 degrees
+        const float mm[3] = {m0, m1, m2};
+        const float mpa = mm[pa], mpb = mm[pb];           // the mean direction projected into the plane
+        auto chart = [&](int ray, float& u, float& v) {
             float o[3], d[3];
             unit_dir(ray, o, d);
+            if (RAY_ORDER_AZIMUTH) {                     // u = signed angle between the projected direction and the projected mean
+                u = atan2f(mpa * d[pb] - mpb * d[pa], mpa * d[pa] + mpb * d[pb]);
+                v = 0.0f;
+                return;
+            }
+            // gnomonic chart about the mean direction, clamped at ~87 degrees
             const float t = fmaxf(d[0] * m0 + d[1] * m1 + d[2] * m2, 0.05f);
             u = (d[0] * e10 + d[1] * e11 + d[2] * e12) / t;
             v = (d[0] * e20 + d[1] * e21 + d[2] * e22) / t;
@@ -163,7 +182,7 @@ __global__ __launch_bounds__(1024) void ray_order_kernel(const float* __restrict
             float l = red2[0][9 + a], h = red2[0][11 + a];
             for (int w = 1; w < 16; ++w) { l = fminf(l, red2[w][9 + a]); h = fmaxf(h, red2[w][11 + a]); }
             blo[a] = l;
-            sc2[a] = (float)(1 << hbits) / fmaxf(h - l, 1e-6f);
+            sc2[a] = (float)(1 << (RAY_ORDER_AZIMUTH ? key_bits : hbits)) / fmaxf(h - l, 1e-6f);
         }
 #pragma unroll
         for (int k = 0; k < ORD_PER_THREAD; ++k) {
@@ -171,11 +190,11 @@ __global__ __launch_bounds__(1024) void ray_order_kernel(const float* __restrict
             if (i < n) {
                 float u, v;
                 chart(base + i, u, v);
-                const unsigned hmax = (1u << hbits) - 1u;
+                const unsigned hmax = (1u << (RAY_ORDER_AZIMUTH ? key_bits : hbits)) - 1u;
                 unsigned x = min((unsigned)fmaxf((u - blo[0]) * sc2[0], 0.f), hmax);
                 unsigned y = min((unsigned)fmaxf((v - blo[1]) * sc2[1], 0.f), hmax);
-                unsigned d = 0;                          // Hilbert index of (x, y) on the 2^hbits x 2^hbits grid
-                for (unsigned sft = 1u << (hbits - 1); sft > 0; sft >>= 1) {
+                unsigned d = RAY_ORDER_AZIMUTH ? x : 0u; // azimuth: the quantised angle is the key; else the Hilbert index of (x, y)
+                for (unsigned sft = RAY_ORDER_AZIMUTH ? 0u : 1u << (hbits - 1); sft > 0; sft >>= 1) {
                     const unsigned rx = (x & sft) ? 1u : 0u, ry = (y & sft) ? 1u : 0u;
                     d += sft * sft * ((3u * rx) ^ ry);
                     if (ry == 0) {
@@ -368,7 +387,7 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
         cpt[k] = -1;
         if (slot < n) {
             const int ui = u0 + slot / per, s = slot % per;
-            const int unit = (RENDER && perm) ? perm[ui] : ui;
+            const int unit = (RENDER && perm) ? perm[(size_t)o * R + ui] : ui;      // the order made for this plane's orientation
             const int64_t pt = RENDER ? (int64_t)unit * S + s : (int64_t)unit * 64 + s;
             if (pt < npts) {
                 float x, y, z;
@@ -745,8 +764,8 @@ extern "C" int eslam_ray_order(const float* rays_o, const float* rays_d, int R, 
     const int chunks = (R + SORT_MAX - 1) / SORT_MAX;
     const int n = R < SORT_MAX ? R : SORT_MAX;         // rays per chunk
     const int key_bits = n <= 1024 ? 12 : n <= 4096 ? 14 : 16;
-    hipLaunchKernelGGL(ray_order_kernel, dim3(chunks), dim3(1024), ((size_t)1 << key_bits) / 2 * sizeof(unsigned), st, rays_o,
-                       rays_d, R, perm, key_bits);
+    hipLaunchKernelGGL(ray_order_kernel, dim3(chunks, ESLAM_RAY_ORDERS), dim3(1024), ((size_t)1 << key_bits) / 2 * sizeof(unsigned), st,
+                       rays_o, rays_d, R, perm, key_bits);
     return eslam_check_launch("ray_order_kernel");
 }
 

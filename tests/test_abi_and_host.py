@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/eslam_hip.h but not exported"
         assert n in _hip.SIGNATURES, f"{n} has no ctypes prototype in myslam_amd/_hip.py"
-    assert lib.eslam_abi_version() == _hip.ABI_VERSION == 4
+    assert lib.eslam_abi_version() == _hip.ABI_VERSION == 5
     assert lib.eslam_bwd_workspace_bytes(262144) > 262144 * 128 * 4
     assert lib.eslam_bwd_workspace_bytes(-1) == -1
 

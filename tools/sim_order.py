@@ -55,14 +55,23 @@ orders = {"given (random pixels)": np.arange(R), "3-D Morton 5 bits/axis (kernel
           "3-D Morton 10 bits/axis": np.argsort(morton3(10), kind='stable'),
           "2-D Morton (PCA plane) 8 bits": np.argsort(pca2(8), kind='stable'),
           "2-D Hilbert (PCA plane) 8 bits": np.argsort(pca2(8, True), kind='stable')}
+# one order PER PLANE ORIENTATION: rays sorted by the azimuth of their direction projected into that plane - rays of one
+# bundle then lie on top of each other in the projection (whatever their angle out of the plane), which is what shares cells
+def azimuth_orders():
+    out = []
+    for (a, b) in [(0, 1), (0, 2), (1, 2)]:
+        out.append(np.argsort(np.arctan2(rd[:, b], rd[:, a]), kind='stable'))
+    return out
+orders["per-orientation azimuth (3 orders)"] = azimuth_orders()
 B = 32
 print(f"{'order':34s} {'distinct cells':>14s} {'carried flushes':>16s} {'boxes > 8192 bins':>18s}")
-for name, order in orders.items():
+for name, order_any in orders.items():
     cells_tot = flush_tot = 0
     big = nbox = 0
     for d in range(2):
         for lvl in range(2):
             for o, (a, b) in enumerate([(0, 1), (0, 2), (1, 2)]):
+                order = order_any[o] if isinstance(order_any, list) else order_any
                 shp = sc.plane_shapes[3 * d + o][lvl]
                 h, w = shp[2], shp[3]
                 x0 = np.floor(np.clip((pn[..., a] + 1) / 2 * (w - 1), 0, w - 1)).astype(np.int64)[order]
