@@ -330,11 +330,7 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hx = lane >> 5, c = lane & 31;   // hx: corner along the MINOR axis
 
-    // Workgroup -> (bundle, plane).  The three planes of one (decoder, level) read the SAME 128-byte segment of every
-    // g_feat row of the bundle; g_feat (134 MB) does not stay in a 4 MB L2, so those three workgroups are made
-    // neighbours in time on ONE XCD (workgroups are dealt round-robin over the 8 XCDs, each with its own L2): with the
-    // plain (bundle, plane) grid 81 % of the walk's row reads missed L2.
-    // The first red_blocks workgroups (a multiple of 8, so that the XCD dealing below is unchanged) are not scatter workgroups:
+    // The first red_blocks workgroups (a multiple of 8) are not scatter workgroups:
     // they sum the decoder-gradient slabs of the decoder backward that ran just before (eslam_dec_reduce.h), beside the
     // scatter's first workgroups instead of as a launch of their own in front of them.
     if (red_blocks > 0 && (int)blockIdx.x < red_blocks) {
@@ -344,16 +340,34 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
     }
     const int bid = (int)blockIdx.x - red_blocks;
     int bidx, pi;
-    if (xcd_map) {
+    // Workgroup -> (bundle, plane), 1-D grid (ESLAM_SC_XCDMAP; measured in profiles/r03/l_*, one ray order per orientation):
+    //   4 (default) bundle-major: the 12 planes of bundle 0, then of bundle 1, ...  The four planes of an orientation bundle the
+    //     same rays and read the four 128-byte segments of the same feature-gradient rows close together in time.
+    //   1 round 2's dealing: the three orientations of one (bundle, decoder, level) as neighbours on ONE XCD - they read the SAME
+    //     segment of the same rows while all planes shared one ray order (81 % of the row reads missed L2 without it); with an
+    //     order per orientation they no longer share rays, and the dealing is 0-10 us slower than 4.
+    //   3 plane-major: every bundle of plane 0, then of plane 1, ...  12-14 us FASTER than 4 on room0's batches (4096 x 64: 86 us)
+    //     and 10-35 us slower on freiburg1_desk's and scene0000's, with identical FETCH / atomic counters: not understood, not the default.
+    //   0 the 2-D (bundle, plane) grid of round 1 (= 3 without the slab reduction in the grid).
+    if (xcd_map == 1) {
         const int xcd = bid & 7, j = bid >> 3;
         const int q = (j / 3) * 8 + xcd;                     // (bundle, segment) pair handled by this XCD slot
         if (q >= nbundles * 4) return;
         const int seg = q & 3;                               // decoder * 2 + level
         bidx = q >> 2;
         pi = (seg >> 1) * 6 + (j % 3) * 2 + (seg & 1);
+    } else if (xcd_map == 3) {
+        bidx = bid % nbundles;
+        pi = bid / nbundles;
+        if (pi >= NPL) return;
+    } else if (xcd_map == 4) {
+        pi = bid % NPL;
+        bidx = bid / NPL;
+        if (bidx >= nbundles) return;
     } else {
         bidx = bid;
         pi = blockIdx.y;                                     // plane index in all_planes order
+        if (bidx >= nbundles) return;
     }
     const int d = pi / 6, o = (pi % 6) >> 1, lvl = pi & 1;
     const eslam_plane_t& P = planes.p[pi];
@@ -796,7 +810,7 @@ static int scatter_bundle_size(int per, int nunits, int* bm_out) {
 // whether the scatter launch of this mode can also run the decoder-gradient slab reduction (the production render path: one
 // kernel, XCD-mapped 1-D grid, 512 threads); the stand-alone dec_grad_reduce_kernel covers the rest
 bool eslam_scatter_can_reduce(bool render) {
-    static const int xcd_map = env_int("ESLAM_SC_XCDMAP", 1), dbg_mode = env_int("ESLAM_SC_MODE", 0), bm = env_int("ESLAM_SC_BUNDLE", 0);
+    static const int xcd_map = env_int("ESLAM_SC_XCDMAP", 4), dbg_mode = env_int("ESLAM_SC_MODE", 0), bm = env_int("ESLAM_SC_BUNDLE", 0);
     static const int off = env_int("ESLAM_SC_NO_REDUCE", 0);
     return render && !eslam_deterministic() && xcd_map && dbg_mode == 0 && bm != 256 && !off;
 }
@@ -837,10 +851,11 @@ int eslam_scatter_v2(const eslam_plane_t* planes, const Bound& bnd, const float*
             return 1;
         }
     static const int counting = env_int("ESLAM_SC_COUNTING", 1);   // A/B switch: 0 = always the bitonic network
-    static const int xcd_map = env_int("ESLAM_SC_XCDMAP", 1);      // A/B switch: 0 = plain (bundle, plane) grid
+    static const int xcd_map = env_int("ESLAM_SC_XCDMAP", 4);      // A/B switch: 0 = plain (bundle, plane) grid
     const int nbundles = (nunits + bundle - 1) / bundle;
     dim3 grid(nbundles, NPL);
-    if (xcd_map) grid = dim3(((nbundles * 4 + 7) / 8) * 8 * 3, 1);
+    if (xcd_map == 3 || xcd_map == 4) grid = dim3(nbundles * NPL, 1);
+    else if (xcd_map == 1) grid = dim3(((nbundles * 4 + 7) / 8) * 8 * 3, 1);
     DecReduceArgs red_args = {};
     int red_blocks = 0;
     if (red) {
