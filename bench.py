@@ -302,6 +302,12 @@ def roofline(prof, n, ms_step, tag="4096x64"):
             ab = tr.get("atomic_bytes")
             e["achieved"] = None if ab is None else ab / t / 1e9
             e["algorithmic_rate_GBs"] = alg_bytes / t / 1e9
+            # the same kernel against HBM on ALL its counter bytes (feature-gradient rows fetched + atomics): with one ray order per
+            # plane orientation (round 3) the atomics halved (73 -> 36 MB at 4096 x 64) and the rows are no longer shared in L2
+            # (95 -> 208 MB fetched): the kernel got faster and moved AWAY from the atomic ceiling - neither fraction is near 1,
+            # it is bound by latency and instruction issue (profiles/r03_pmc_sq_summary_*.txt)
+            tb = tr.get("traffic_bytes")
+            e["hbm_frac_on_counter_bytes"] = None if tb is None else tb / t / 1e9 / HBM_PEAK_GBS
         elif bound == "hbm":
             tb = tr.get("traffic_bytes")
             e["achieved"] = None if tb is None else tb / t / 1e9
