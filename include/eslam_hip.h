@@ -35,6 +35,7 @@ extern "C" {
 #define ESLAM_N_PLANES 12
 #define ESLAM_MAX_SAMPLES 256   /* samples per ray supported by the per-ray kernels                  */
 #define ESLAM_RAY_ORDERS 3      /* eslam_ray_order writes one order per plane orientation (xy, xz, yz)    */
+#define ESLAM_RAY_ORDER_WORDS(R) (ESLAM_RAY_ORDERS * (int64_t)(R) + 4)   /* int32 words of its output buffer */
 /* floats in the flat decoder-gradient vector, in the order of eslam_decoders_t (beta excluded)      */
 #define ESLAM_N_DEC_PARAMS (2 * (16 * 64 + 16 + 16 * 16 + 16) + (1 * 16 + 1) + (3 * 16 + 3))
 
@@ -179,8 +180,10 @@ int eslam_render_fwd_lowp(const eslam_plane_t* planes_f16, const eslam_decoders_
                           const float* rays_o, const float* rays_d, const float* z_vals, int R, int S, float* depth,
                           float* rgb, float* sdf, eslam_stream_t stream);
 
-/* Ray orders for eslam_render_bwd's plane-gradient scatter (and, optionally, eslam_render_fwd): perm [ESLAM_RAY_ORDERS][R]
- * <- three permutations of the ray ids, one per plane orientation (xy, xz, yz).  Rays that share one origin (one camera's
+/* Ray orders for eslam_render_bwd's plane-gradient scatter (and, optionally, eslam_render_fwd): perm, a buffer of
+ * ESLAM_RAY_ORDER_WORDS(R) int32 words, <- [ESLAM_RAY_ORDERS][R] permutations followed by 3 floats (+ 1 pad): the angular
+ * extent of the batch's fan of rays in each plane, which the scatter reads to choose its workgroup order.  Three
+ * permutations of the ray ids, one per plane orientation (xy, xz, yz).  Rays that share one origin (one camera's
  * batch) are sorted, for orientation o, by the azimuth of their direction projected into that plane - the rays of a bundle
  * then cover a thin wedge of the plane and share its cells; batches with several origins get the same order three times
  * (a Morton key of the point one metre along each ray).  Single-pass counting sorts, chunks of 8192 rays.  Depends only on the

@@ -16,6 +16,11 @@ LIB_PATH = os.environ.get("ESLAM_HIP_LIB") or os.path.join(_HERE, "lib", "libesl
 
 ABI_VERSION = 5              # ESLAM_ABI_VERSION
 RAY_ORDERS = 3               # ESLAM_RAY_ORDERS: eslam_ray_order writes one order per plane orientation
+
+
+def ray_order_words(R):
+    """ESLAM_RAY_ORDER_WORDS(R): int32 words of eslam_ray_order's output (the three orders + the fan's extent per plane)."""
+    return RAY_ORDERS * int(R) + 4
 N_DEC_PARAMS = 2692
 N_PLANES = 12
 

@@ -957,7 +957,7 @@ static int render_bwd_impl(const char* who, const eslam_plane_t* planes, const e
     const int* perm = ray_order;
     bool scatter_runs = false;         // the order bundles rays for the plane-gradient scatter: tracking (no plane gradients) has no use for it
     for (int i = 0; i < NPL; ++i) scatter_runs = scatter_runs || planes[i].grad != nullptr;
-    if (!perm && scatter_runs && S >= ESLAM_RAY_ORDERS) {      // the forward pass did not leave the orders: compute them here (3 R ints in a region of R S)
+    if (!perm && scatter_runs && (int64_t)ESLAM_RAY_ORDER_WORDS(R) <= N) {      // the forward pass did not leave the orders: compute them here (in a region of R S ints)
         int* own = (int*)(ws + align256(N * 16) + align256(N * 512) + align256(slab_region_bytes(N)));
         if (int rc = eslam_ray_order(rays_o, rays_d, R, own, st)) return rc;
         perm = own;

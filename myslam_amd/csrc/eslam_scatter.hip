@@ -78,6 +78,7 @@ __global__ __launch_bounds__(1024) void ray_order_kernel(const float* __restrict
     // one axis, so a square patch of the image (the Hilbert order: one order for all planes) spreads over many more cells of
     // each plane than a thin wedge does.  tools/sim_order.py, bench rays: 58.8 k cell flushes against 135 k.
     const int orient = blockIdx.y;
+    float* const fan = (float*)(perm + (size_t)ESLAM_RAY_ORDERS * R);      // [ESLAM_RAY_ORDERS] angular extent of the fan in each plane (0: unknown)
     perm += (size_t)orient * R;
     const int pa = orient == 2 ? 1 : 0, pb = orient == 0 ? 1 : 2;       // the plane's two axes
 
@@ -183,6 +184,8 @@ __global__ __launch_bounds__(1024) void ray_order_kernel(const float* __restrict
             for (int w = 1; w < 16; ++w) { l = fminf(l, red2[w][9 + a]); h = fmaxf(h, red2[w][11 + a]); }
             blo[a] = l;
             sc2[a] = (float)(1 << (RAY_ORDER_AZIMUTH ? key_bits : hbits)) / fmaxf(h - l, 1e-6f);
+            // the fan's angular extent in this plane (radians), for the scatter's choice of grid order; the first chunk speaks for the batch
+            if (a == 0 && tid == 0 && blockIdx.x == 0) fan[orient] = RAY_ORDER_AZIMUTH ? h - l : 0.0f;
         }
 #pragma unroll
         for (int k = 0; k < ORD_PER_THREAD; ++k) {
@@ -208,6 +211,7 @@ __global__ __launch_bounds__(1024) void ray_order_kernel(const float* __restrict
             __builtin_amdgcn_sched_barrier(0);           // one ray at a time keeps the register pressure down
         }
     } else {
+        if (tid == 0 && blockIdx.x == 0) fan[orient] = 0.0f;      // several origins: no fan
         float scale[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -361,9 +365,21 @@ __global__ __launch_bounds__(NT) void scatter_sort_kernel(const PlaneSet planes,
         pi = bid / nbundles;
         if (pi >= NPL) return;
     } else if (xcd_map == 4) {
-        pi = bid % NPL;
-        bidx = bid / NPL;
-        if (bidx >= nbundles) return;
+        // auto: plane-major for a WIDE fan of rays from one origin, bundle-major otherwise.  Measured (profiles/r03/n_*): with the
+        // same pixels through lenses of different focal length, bundle-major costs 110 / 97 / 83 / 81 / 80 us at a horizontal field
+        // of view of 118 / 90 / 67 / 53 / 37 degrees where plane-major stays at 99 / 87 / 87 / 88 / 90 - the orders cross near 80
+        // degrees.  The fan's extent in each plane comes from the ray ordering kernel, through device memory (no host round trip);
+        // the SECOND largest of the three is the criterion (the largest is ~360 degrees in the plane the camera looks down on).
+        bool plane_major = false;
+        if (RENDER && perm) {
+            const float* fan = (const float*)(perm + (size_t)ESLAM_RAY_ORDERS * R);
+            const float f0 = fan[0], f1 = fan[1], f2 = fan[2];
+            const float second = fmaxf(fminf(f0, f1), fminf(fmaxf(f0, f1), f2));
+            plane_major = second >= 1.4f;
+        }
+        if (plane_major) { bidx = bid % nbundles; pi = bid / nbundles; }
+        else { pi = bid % NPL; bidx = bid / NPL; }
+        if (bidx >= nbundles || pi >= NPL) return;
     } else {
         bidx = bid;
         pi = blockIdx.y;                                     // plane index in all_planes order

@@ -163,7 +163,7 @@ public:
         if (needs) {
             raw_rgb = at::empty({R, S, 3}, opt);
             feat = at::empty({R * S, 128}, opt);
-            perm = at::empty({planes_grad ? ESLAM_RAY_ORDERS * R : 0}, opt.dtype(at::kInt));     // the scatter's bundling orders: only planes with a gradient need them
+            perm = at::empty({planes_grad ? ESLAM_RAY_ORDER_WORDS(R) : 0}, opt.dtype(at::kInt));     // the scatter's bundling orders: only planes with a gradient need them
         }
         if (io.relayout && R > 0) {
             auto cl = alloc_plane_grads(planes, Layout::channels_last);

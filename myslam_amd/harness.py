@@ -21,7 +21,7 @@ _SEPARATE_LOSS = os.environ.get("ESLAM_SEPARATE_LOSS", "0") == "1"
 
 class Workload:
     def __init__(self, scene_name, R, n_strat, n_imp, device, zero_frac=0.0, seed=0, channels_last=True,
-                 rays_grad=False, planes="normal", model_seed=0, shard=None, state="initial", cams=1):
+                 rays_grad=False, planes="normal", model_seed=0, shard=None, state="initial", cams=1, focal_scale=1.0):
         """seed: image / pixel choice of this rank's rays; model_seed: planes and decoders (same on every rank of a
         data-parallel job, whose replicas must be identical).  shard = (rank, world): build the WHOLE batch (give every
         rank the same seed) and keep this rank's contiguous slice of its rays (parallel.shard_slice) - the ray-sharded
@@ -76,7 +76,8 @@ class Workload:
                 c2ws[k, :3, 3] += torch.tensor([math.sin(a), 0.0, math.cos(a)]) * half
         c2ws = c2ws.to(dev)
         with torch.no_grad():
-            ro, rd, gd, gc = get_samples_at(idx, 0, sc.H, 0, sc.W, R // cams, sc.H, sc.W, sc.fx, sc.fy, sc.cx, sc.cy, c2ws,
+            # (focal_scale: profiling knob - the same pixels through a longer lens, i.e. a narrower fan of rays)
+            ro, rd, gd, gc = get_samples_at(idx, 0, sc.H, 0, sc.W, R // cams, sc.H, sc.W, sc.fx * focal_scale, sc.fy * focal_scale, sc.cx, sc.cy, c2ws,
                                             depth_img, color_img)
             inside = ops.aabb_exit(ro, rd, ops.bound_to_host(sc.bound)) >= gd           # Mapper.py:322-332
         ro, rd, gd, gc = ro[inside], rd[inside], gd[inside], gc[inside]

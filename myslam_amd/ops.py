@@ -260,7 +260,7 @@ _PRECLEAR = os.environ.get("ESLAM_PRECLEAR", "1") == "1"
 
 def ray_order_async(rays_o, rays_d, grad_planes=None):
     """Launch eslam_ray_order on a side stream (it depends only on the rays, so it overlaps the samplers).
-    Returns (perm int32 [3 R]: one order per plane orientation, stream to join before the order is used[, gradient views]).
+    Returns (perm int32 [3 R + 4]: one order per plane orientation + the fan's extent, stream to join before the order is used[, gradient views]).
     grad_planes: the 12 planes when the coming backward pass will need their gradient buffer: it is allocated here and
     cleared at the HEAD of the side stream, beside the samplers (27 - 70 MB: 6 - 15 us in front of the backward pass
     otherwise; beside the forward kernel the memset's writes slowed the forward down by more than that)."""
@@ -272,7 +272,7 @@ def ray_order_async(rays_o, rays_d, grad_planes=None):
     side = _side_streams.get(dev.index)
     if side is None:
         side = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
-    perm = torch.empty(_hip.RAY_ORDERS * R, dtype=torch.int32, device=dev)      # one order per plane orientation
+    perm = torch.empty(_hip.ray_order_words(R), dtype=torch.int32, device=dev)      # one order per plane orientation (+ the fan's extent)
     pre = None
     if grad_planes is not None and _PRECLEAR and _grad_sink is None and not _keep_layout:      # (keep_layout: a sink will take the gradients)
         pre = _alloc_plane_grads(grad_planes, zero=False)      # on the caller's stream: its allocator's memory

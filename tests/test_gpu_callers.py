@@ -282,7 +282,9 @@ def test_ray_order_is_a_permutation_and_groups_neighbours(cameras, R):
     rd = d.to(dev)
     perm, side = ops.ray_order_async(ro, rd)
     torch.cuda.current_stream().wait_stream(side)
-    assert perm.numel() == 3 * R                                # one order per plane orientation (xy, xz, yz)
+    assert perm.numel() == 3 * R + 4                            # one order per plane orientation (xy, xz, yz) + the fan's extent
+    fan = perm[3 * R:3 * R + 3].view(torch.float32).cpu()
+    assert (fan > 0.1).all() and (fan < 6.3).all() if cameras == 1 else (fan == 0).all()
     for o, (a, b) in enumerate([(0, 1), (0, 2), (1, 2)]):
         p = perm[o * R:(o + 1) * R].cpu().long()
         for lo in range(0, R, 8192):                            # chunks are ordered independently

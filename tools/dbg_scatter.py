@@ -11,7 +11,8 @@ a = sys.argv[1:]
 lowp = len(a) > 5 and a[5] == 'lowp'
 cams = int(a[5][4:]) if len(a) > 5 and a[5].startswith('cams') else 1
 wl = harness.make_workload(a[0] if a else 'room0', int(a[1]) if a else 4096, int(a[2]) if a else 56, int(a[3]) if a else 8,
-                           device=dev, zero_frac=float(a[4]) if len(a) > 4 else 0.0, cams=cams)
+                           device=dev, zero_frac=float(a[4]) if len(a) > 4 else 0.0, cams=cams,
+                           focal_scale=float(os.environ.get('DBG_FOCAL_SCALE', '1')))
 if cams > 1: print(f"{cams} cameras, {wl.R} rays kept of the batch")
 step = wl.step
 if lowp:
