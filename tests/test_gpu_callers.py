@@ -269,8 +269,9 @@ def test_loss_set_sizes_equal_the_forward_kernels_counts():
 
 @pytest.mark.parametrize("cameras,R", [(1, 4096), (1, 77), (3, 3000), (1, 9000)])
 def test_ray_order_is_a_permutation_and_groups_neighbours(cameras, R):
-    """eslam_ray_order: a permutation of every chunk of 8192 rays, for one origin (2-D Hilbert key of the direction) and
-    several (3-D Morton key); consecutive rays of the order point in nearby directions."""
+    """eslam_ray_order: three permutations (one per plane orientation) of every chunk of 8192 rays - for one origin keyed on the
+    azimuth of the direction projected into the plane, for a camera-major batch of several origins on (camera, azimuth), for
+    origins in random order on a 3-D Morton code."""
     from myslam_amd import ops
     dev = _dev()
     g = torch.Generator().manual_seed(cameras * 1000 + R)
@@ -302,7 +303,27 @@ def test_ray_order_is_a_permutation_and_groups_neighbours(cameras, R):
             # non-decreasing up to the key's quantisation, except at the ONE seam where the angle wraps (the kernel measures it
             # against the chunk's own projected mean direction: a camera looking along the plane's normal fills the circle)
             assert int(((ang[p[1:n1]] - ang[p[:n1 - 1]]) < -2e-3).sum()) <= 1
-    # (several origins: the three orders are the same Morton order up to the arbitrary order inside a key's cell)
+    # (several origins in random order: the three orders are the same Morton order up to the arbitrary order inside a key's cell)
+    if cameras > 1 and R <= 8192:
+        # a keyframe window as get_samples builds it: camera-major.  Order o then keeps every camera's rays together and sorts
+        # them by the azimuth of their direction projected into plane o, against the camera's own projected mean direction
+        cam_sorted, _ = torch.sort(cam)
+        ro2 = org[cam_sorted].to(dev)
+        perm2, side2 = ops.ray_order_async(ro2, rd)
+        torch.cuda.current_stream().wait_stream(side2)
+        assert float(perm2[3 * R:3 * R + 3].view(torch.float32).abs().max()) == 0.0
+        for o, (a, b) in enumerate([(0, 1), (0, 2), (1, 2)]):
+            p = perm2[o * R:(o + 1) * R].cpu().long()
+            assert torch.equal(torch.sort(p).values, torch.arange(R))
+            assert bool((cam_sorted[p][1:] >= cam_sorted[p][:-1]).all())            # cameras stay together, in their order
+            dn = torch.nn.functional.normalize(d, dim=1)
+            for c in range(cameras):
+                sel = p[cam_sorted[p] == c]
+                if len(sel) < 50:
+                    continue
+                m = dn[cam_sorted == c].sum(0)
+                ang = torch.atan2(m[a] * d[sel, b] - m[b] * d[sel, a], m[a] * d[sel, a] + m[b] * d[sel, b])
+                assert int(((ang[1:] - ang[:-1]) < -0.05).sum()) <= 1       # sorted up to the key's quantisation, one wrap at most
 
 
 def test_in_kernel_jitter_is_uniform_fresh_per_step_and_reproducible():
