@@ -872,7 +872,9 @@ extern "C" int eslam_ray_order(const float* rays_o, const float* rays_d, int R, 
     if (int rc = eslam_scatter_v2_init()) return rc;
     const int chunks = (R + SORT_MAX - 1) / SORT_MAX;
     const int n = R < SORT_MAX ? R : SORT_MAX;         // rays per chunk
-    const int key_bits = n <= 1024 ? 12 : n <= 4096 ? 14 : 16;
+    // (16-bit keys were for the 2-D Hilbert order of round 2: 8 bits per axis.  The azimuth keys are one-dimensional: 14 bits = two
+    // bins per ray at 8192 rays, and the histogram's zero fill and scan - 63 us of this kernel at 5000 rays with 16 bits - shrink 4x)
+    const int key_bits = n <= 1024 ? 12 : 14;
     static const int max_cams = env_int("ESLAM_RAY_ORDER_CAMERAS", 32);      // A/B switch: 0 = several origins always get the Morton order
     hipLaunchKernelGGL(ray_order_kernel, dim3(chunks, ESLAM_RAY_ORDERS), dim3(1024), ((size_t)1 << key_bits) / 2 * sizeof(unsigned), st,
                        rays_o, rays_d, R, perm, key_bits, max_cams);
