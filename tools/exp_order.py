@@ -1,6 +1,8 @@
-"""Experiment: does a 2-D Hilbert ray order (single camera) beat the kernel's 3-D Morton order on the GPU?
-Computes the permutation on the CPU and injects it in place of eslam_ray_order."""
+"""Experiment (round 1): does a 2-D Hilbert ray order (single camera) beat the kernel's order on the GPU?
+Computes the permutation on the CPU and injects it in place of eslam_ray_order - as all THREE per-orientation orders of the
+ABI-5 buffer ([3][R] + the fan's extent, here 0 = bundle-major grid; ESLAM_TORCH_EXT=0: the injection hooks the Python glue)."""
 import ctypes, os, sys, numpy as np, torch
+os.environ.setdefault('ESLAM_TORCH_EXT', '0')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from myslam_amd import harness, ops, _hip
 dev = torch.device('cuda:0')
@@ -26,7 +28,11 @@ def hilbert_perm(bits=8):
         sw = ry == 0
         x, y = np.where(sw, y, x), np.where(sw, x, y)
         s >>= 1
-    return torch.from_numpy(np.argsort(d, kind='stable').astype(np.int32)).to(dev)
+    return as_orders(torch.from_numpy(np.argsort(d, kind='stable').astype(np.int32)).to(dev))
+
+
+def as_orders(p):          # the buffer eslam_ray_order fills: three orders + 4 words (the fan's extent per plane: zeros)
+    return torch.cat([p, p, p, torch.zeros(4, dtype=torch.int32, device=dev)])
 
 def measure(label):
     buf = (ctypes.c_float * 12)()
@@ -38,12 +44,12 @@ def measure(label):
     lib.eslam_profile_enable(0)
     print(label, {lib.eslam_profile_name(i).decode(): round(sorted(v)[7] * 1e3, 1) for i, v in acc.items()}, 'us', flush=True)
 
-measure('3-D Morton (kernel)')
+measure('kernel (per-orientation azimuth)')
 perm = hilbert_perm()
 side = torch.cuda.Stream()
 orig = ops.ray_order_async
-ops.ray_order_async = lambda ro, rd: (perm, side)
+ops.ray_order_async = lambda ro, rd, planes=None: (perm, side)
 import myslam_amd.src.utils.Renderer as R
 measure('2-D Hilbert (injected)')
-ops.ray_order_async = lambda ro, rd: (torch.arange(4096, dtype=torch.int32, device=dev), side)
+ops.ray_order_async = lambda ro, rd, planes=None: (as_orders(torch.arange(4096, dtype=torch.int32, device=dev)), side)
 measure('unsorted (identity)')
