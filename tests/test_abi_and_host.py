@@ -42,6 +42,12 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_hip.DecodersDesc) == 13 * 8
     assert ctypes.sizeof(_hip.AdamTensor) == 4 * 8 + 8 + 8
     assert _hip.N_DEC_PARAMS == 2 * (16 * 64 + 16 + 16 * 16 + 16) + 17 + 51
+    # the ray-order buffer (ABI 5): the binding's size formula must be the header's macro
+    import re
+    hdr = open(os.path.join(ROOT, "include", "eslam_hip.h")).read()
+    assert int(re.search(r"#define ESLAM_RAY_ORDERS (\d+)", hdr).group(1)) == _hip.RAY_ORDERS
+    m = re.search(r"#define ESLAM_RAY_ORDER_WORDS\(R\) \(ESLAM_RAY_ORDERS \* \(int64_t\)\(R\) \+ (\d+)\)", hdr)
+    assert m and _hip.ray_order_words(1000) == _hip.RAY_ORDERS * 1000 + int(m.group(1))
 
 
 def test_missing_library_fails_loudly(tmp_path):

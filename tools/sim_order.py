@@ -6,9 +6,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from _cpu_samples import bench_samples
 
-R, ns, ni = 4096, 56, 8
+# python tools/sim_order.py [scene rays n_strat n_imp]
+R, ns, ni = (int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (4096, 56, 8)
 S = ns + ni
-sc, idx, ro, rd, z, pn = bench_samples(R, ns, ni)
+sc, idx, ro, rd, z, pn = bench_samples(R, ns, ni, scene=sys.argv[1] if len(sys.argv) > 1 else "room0")
 
 def spread(v, bits):
     out = np.zeros_like(v, dtype=np.uint64)
@@ -63,7 +64,7 @@ def azimuth_orders():
         out.append(np.argsort(np.arctan2(rd[:, b], rd[:, a]), kind='stable'))
     return out
 orders["per-orientation azimuth (3 orders)"] = azimuth_orders()
-B = 32
+B = 2048 // S
 print(f"{'order':34s} {'distinct cells':>14s} {'carried flushes':>16s} {'boxes > 8192 bins':>18s}")
 for name, order_any in orders.items():
     cells_tot = flush_tot = 0
